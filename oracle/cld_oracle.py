@@ -1,0 +1,280 @@
+"""ORACLE (test infrastructure, NOT product code) -- CPU restatement of the CLD
+latent-diffusion sampling path in plain fp32 PyTorch ops.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this file; the product package never does (it fails loudly when the HIP
+library is missing instead of falling back to anything here).
+
+Parity status: PINNED.  Every function below is checked in
+`tests/test_oracle_golden.py` against golden vectors under `tests/golden/`,
+which `oracle/make_golden.py` produced by importing the reference's own,
+unmodified files from /root/reference in the build container (torch 2.10 CPU,
+1 thread) with weights from `synth.py` pushed in through `load_state_dict`.
+
+Each function cites the reference file:line it restates.  Nothing here is
+copied from the reference: the reference is an `nn.Module` tree driven by
+einops layers; this is a flat functional walk over a `state_dict`.
+
+All tensors are torch CPU tensors; `dtype` may be float32 (the parity dtype) or
+float64 (used only to report the fp32 rounding floor next to parity numbers).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- #
+# a-1  schedule buffers
+# --------------------------------------------------------------------------- #
+def cosine_betas(n: int, s: float = 0.008) -> Tensor:
+    """src/tbsim/models/diffuser_helpers.py:451-462 -- float64 NumPy cosine
+    schedule, clipped to [0, 0.999], then cast to fp32."""
+    steps = n + 1
+    x = np.linspace(0, steps, steps)
+    ac = np.cos(((x / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    ac = ac / ac[0]
+    betas = 1 - (ac[1:] / ac[:-1])
+    return torch.tensor(np.clip(betas, a_min=0, a_max=0.999), dtype=torch.float32)
+
+
+def schedule(n: int = 100) -> Dict[str, Tensor]:
+    """models/dm/dm_model.py:29-56 -- the buffers the sampler reads
+    (x_t_cof, noise_cof, posterior_log_variance_clipped) plus the ones they
+    derive from, all computed in fp32 exactly in the reference's op order."""
+    betas = cosine_betas(n)
+    alphas = 1.0 - betas
+    ac = torch.cumprod(alphas, 0)
+    ac_prev = torch.cat([torch.ones(1), ac[:-1]])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+    return {
+        "betas": betas,
+        "alphas_cumprod": ac,
+        "alphas_cumprod_prev": ac_prev,
+        "sqrt_alphas_cumprod": torch.sqrt(ac),
+        "sqrt_one_minus_alphas_cumprod": torch.sqrt(1.0 - ac),
+        "posterior_variance": post_var,
+        "posterior_log_variance_clipped": torch.log(torch.clamp(post_var, min=1e-20)),
+        "x_t_cof": torch.sqrt(1.0 / alphas),
+        "noise_cof": betas / torch.sqrt(alphas - ac * alphas),
+    }
+
+
+# --------------------------------------------------------------------------- #
+# a-4  U-Net
+# --------------------------------------------------------------------------- #
+def sinusoidal_emb(t: Tensor, dim: int = 32, dtype=torch.float32) -> Tensor:
+    """diffuser_helpers.py:25-32 -- [sin(t*w_k), cos(t*w_k)], w_k = exp(-k ln(1e4)/(dim/2-1))."""
+    half = dim // 2
+    w = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    e = t[:, None] * w[None, :]          # int64 * fp32 -> fp32, as in the reference
+    return torch.cat((e.sin(), e.cos()), dim=-1).to(dtype)
+
+
+def conv_block(x: Tensor, w: Dict[str, Tensor], p: str) -> Tensor:
+    """diffuser_helpers.py:50-67 -- Conv1d(k, pad=k//2) -> GroupNorm(8, eps 1e-5) -> Mish."""
+    cw = w[p + ".block.0.weight"]
+    y = F.conv1d(x, cw, w[p + ".block.0.bias"], padding=cw.shape[-1] // 2)
+    y = F.group_norm(y, 8, w[p + ".block.2.weight"], w[p + ".block.2.bias"], eps=1e-5)
+    return F.mish(y)
+
+
+def res_block(x: Tensor, tc: Tensor, w: Dict[str, Tensor], p: str) -> Tensor:
+    """temporal.py:16-45 -- out = CB1(CB0(x) + Linear(Mish(tc))[:, :, None]) + res(x)."""
+    bias = F.linear(F.mish(tc), w[p + ".time_mlp.1.weight"], w[p + ".time_mlp.1.bias"])
+    h = conv_block(x, w, p + ".blocks.0") + bias[:, :, None]
+    h = conv_block(h, w, p + ".blocks.1")
+    rw = w.get(p + ".residual_conv.weight")
+    r = x if rw is None else F.conv1d(x, rw, w[p + ".residual_conv.bias"])
+    return h + r
+
+
+def unet_forward(w: Dict[str, Tensor], x: Tensor, cond: Tensor, t: Tensor,
+                 taps: Optional[dict] = None) -> Tensor:
+    """temporal.py:122-180 -- x [B,52,4], cond [B,256], t [B] int64 -> eps [B,52,4].
+    `taps`, when given, collects named intermediate activations ([B,C,L] layout)."""
+    dt = x.dtype
+    h = x.transpose(1, 2)                                   # temporal.py:139
+    te = sinusoidal_emb(t, w["model.time_mlp.1.weight"].shape[1], dt)
+    te = F.linear(te, w["model.time_mlp.1.weight"], w["model.time_mlp.1.bias"])
+    te = F.linear(F.mish(te), w["model.time_mlp.3.weight"], w["model.time_mlp.3.bias"])
+    tc = torch.cat([te, cond], dim=-1)                      # temporal.py:146
+    skips = []
+    n_down = 0
+    while f"model.downs.{n_down}.0.time_mlp.1.weight" in w:
+        n_down += 1
+    for i in range(n_down):
+        h = res_block(h, tc, w, f"model.downs.{i}.0")
+        h = res_block(h, tc, w, f"model.downs.{i}.1")
+        if taps is not None:
+            taps[f"downs.{i}.1"] = h
+        skips.append(h)
+        dw = w.get(f"model.downs.{i}.2.conv.weight")
+        if dw is not None:                                  # Downsample1d, diffuser_helpers.py:34-40
+            h = F.conv1d(h, dw, w[f"model.downs.{i}.2.conv.bias"], stride=2, padding=1)
+            if taps is not None:
+                taps[f"downs.{i}.2"] = h
+    h = res_block(h, tc, w, "model.mid_block1")
+    h = res_block(h, tc, w, "model.mid_block2")
+    if taps is not None:
+        taps["mid_block2"] = h
+    i = 0
+    while f"model.ups.{i}.0.time_mlp.1.weight" in w:
+        h = torch.cat((h, skips.pop()), dim=1)              # temporal.py:164
+        h = res_block(h, tc, w, f"model.ups.{i}.0")
+        h = res_block(h, tc, w, f"model.ups.{i}.1")
+        if taps is not None:
+            taps[f"ups.{i}.1"] = h
+        # Upsample1d, diffuser_helpers.py:42-48: ConvTranspose1d(k4, s2, p1)
+        h = F.conv_transpose1d(h, w[f"model.ups.{i}.2.conv.weight"],
+                               w[f"model.ups.{i}.2.conv.bias"], stride=2, padding=1)
+        if taps is not None:
+            taps[f"ups.{i}.2"] = h
+        i += 1
+    h = conv_block(h, w, "model.final_conv.0")              # temporal.py:117-120
+    if taps is not None:
+        taps["final_conv.0"] = h
+    h = F.conv1d(h, w["model.final_conv.1.weight"], w["model.final_conv.1.bias"])
+    return h.transpose(1, 2)                                # temporal.py:176
+
+
+# --------------------------------------------------------------------------- #
+# a-3 / a-2 / a-8  DDPM update, sampling loop, log-prob
+# --------------------------------------------------------------------------- #
+def ddpm_step(w, sched, x: Tensor, cond: Tensor, i: int, z: Tensor):
+    """dm_model.py:144-163 -- one ancestral step at timestep i with caller noise z.
+    Returns (x_{t-1}, mean, sigma scalar tensor)."""
+    B = x.shape[0]
+    t = torch.full((B,), i, dtype=torch.long)
+    eps = unet_forward(w, x, cond, t)
+    dt = x.dtype
+    mean = sched["x_t_cof"][i].to(dt) * x - sched["noise_cof"][i].to(dt) * eps
+    sigma = (0.5 * sched["posterior_log_variance_clipped"][i].to(dt)).exp()
+    nz = 0.0 if i == 0 else 1.0                             # nonzero_mask, dm_model.py:151
+    return mean + (nz * sigma) * z, mean, sigma
+
+
+def normal_log_prob_mean(x: Tensor, mean: Tensor, sigma: Tensor) -> Tensor:
+    """torch.distributions.Normal(mean, sigma).log_prob(x).mean((1,2)), dm_model.py:130-132,170-173:
+    -((x-mean)^2)/(2 sigma^2) - log(sigma) - log(sqrt(2 pi))."""
+    var = sigma ** 2
+    lp = -((x - mean) ** 2) / (2 * var) - sigma.log() - math.log(math.sqrt(2 * math.pi))
+    return lp.mean(dim=(1, 2))
+
+
+def sample(w, sched, x_T: Tensor, noise: Tensor, cond: Tensor, n_steps: Optional[int] = None) -> dict:
+    """dm_model.py:103-142 -- loop i = n-1..0; noise[s] feeds iteration s (i = n-1-s).
+    Returns pred_traj (x0), x1, log_prob_final."""
+    n = int(sched["x_t_cof"].shape[0]) if n_steps is None else n_steps
+    x = x_T
+    x1 = None
+    out = {}
+    for s, i in enumerate(reversed(range(n))):
+        x, mean, sigma = ddpm_step(w, sched, x, cond, i, noise[s])
+        if i == 1:
+            x1 = x.clone()
+        if i == 0:
+            out["pred_traj"] = x.clone()
+            out["log_prob_final"] = normal_log_prob_mean(x, mean, sigma)
+    out["x1"] = x1
+    return out
+
+
+def log_prob(w, sched, x_t: Tensor, x_tm1: Tensor, cond: Tensor, i: int) -> Tensor:
+    """dm_model.py:165-174 -- log N(x_{t-1}; mean(x_t, eps), sigma_t) averaged over (T, D)."""
+    B = x_t.shape[0]
+    t = torch.full((B,), i, dtype=torch.long)
+    eps = unet_forward(w, x_t, cond, t)
+    dt = x_t.dtype
+    mean = sched["x_t_cof"][i].to(dt) * x_t - sched["noise_cof"][i].to(dt) * eps
+    sigma = (0.5 * sched["posterior_log_variance_clipped"][i].to(dt)).exp()
+    return normal_log_prob_mean(x_tm1, mean, sigma)
+
+
+# --------------------------------------------------------------------------- #
+# a-5  LSTM-VAE decoder
+# --------------------------------------------------------------------------- #
+def lstm_decode(w: Dict[str, Tensor], z: Tensor, cond: Tensor) -> Tensor:
+    """models/vae/lstm_vae.py:44-52 -- h0 = cond2hidden(cond) for both layers, c0 = 0,
+    2-layer LSTM(4->64) (gate rows i,f,g,o), hid2act 64->2.  z [B,52,4] -> [B,52,2]."""
+    B, T, _ = z.shape
+    H = w["lstm_dec.lstm.weight_hh_l0"].shape[1]
+    h0 = F.linear(cond, w["lstm_dec.cond2hidden.weight"], w["lstm_dec.cond2hidden.bias"])
+    h = [h0.clone(), h0.clone()]
+    c = [torch.zeros(B, H, dtype=z.dtype), torch.zeros(B, H, dtype=z.dtype)]
+    outs = []
+    for t in range(T):
+        inp = z[:, t]
+        for l in range(2):
+            g = (F.linear(inp, w[f"lstm_dec.lstm.weight_ih_l{l}"], w[f"lstm_dec.lstm.bias_ih_l{l}"])
+                 + F.linear(h[l], w[f"lstm_dec.lstm.weight_hh_l{l}"], w[f"lstm_dec.lstm.bias_hh_l{l}"]))
+            gi, gf, gg, go = g.chunk(4, dim=1)
+            c[l] = torch.sigmoid(gf) * c[l] + torch.sigmoid(gi) * torch.tanh(gg)
+            h[l] = torch.sigmoid(go) * torch.tanh(c[l])
+            inp = h[l]
+        outs.append(inp)
+    y = torch.stack(outs, dim=1)
+    return F.linear(y, w["lstm_dec.hid2act.weight"], w["lstm_dec.hid2act.bias"])
+
+
+# --------------------------------------------------------------------------- #
+# a-6 / a-7  descale + unicycle roll-out
+# --------------------------------------------------------------------------- #
+NORM_MEAN = (13.162, -0.13891, 5.0223, -0.0046415, -0.0080072, -0.0013546)   # config.yaml:162
+NORM_STD = (13.0717, 2.2462, 3.6187, 0.2210, 2.5770, 0.0840)                 # config.yaml:163
+DYN = dict(acce_lo=-10.0, acce_hi=8.0, v_lo=-10.0, v_hi=30.0,                 # config.yaml:134-141,
+           max_steer=0.5, max_yawvel=2 * math.pi, dt=0.1)                     # unicycle.py:8-19
+
+
+def unicycle_parallel(cs: Tensor, act: Tensor, dyn: dict = DYN) -> Tensor:
+    """diffuser_helpers.py:541-639, mode='parallel' -- cs [B,4]=(x,y,v,yaw), act [B,T,2]
+    (acc, yaw-rate; descaled) -> [B,T,4].  The reference builds tril matrices and bmm's;
+    the sums below are the same inclusive prefix sums (v is clipped AFTER the sum)."""
+    dt = dyn["dt"]
+    acc = act[..., 0].clamp(dyn["acce_lo"], dyn["acce_hi"])
+    v_raw = torch.cumsum(torch.cat((cs[:, 2:3], acc * dt), dim=1), dim=1)      # [B,T+1]
+    v = v_raw.clamp(dyn["v_lo"], dyn["v_hi"])
+    v_avg = 0.5 * (v[:, :-1] + v[:, 1:])
+    v_prev = v[:, :-1]
+    yb = torch.minimum(dyn["max_steer"] * v_prev.abs(),
+                       dyn["max_yawvel"] / v_prev.abs().clamp(min=0.1)).clamp(min=0.1)
+    yr = torch.maximum(torch.minimum(act[..., 1], yb), -yb)
+    yaw_full = torch.cumsum(torch.cat((cs[:, 3:4], yr * dt), dim=1), dim=1)
+    yaw_prev = yaw_full[:, :-1]
+    vx = v_avg * torch.cos(yaw_prev)
+    vy = v_avg * torch.sin(yaw_prev)
+    xs = torch.cumsum(torch.cat((cs[:, 0:1], vx * dt), dim=1), dim=1)[:, 1:]
+    ys = torch.cumsum(torch.cat((cs[:, 1:2], vy * dt), dim=1), dim=1)[:, 1:]
+    return torch.stack((xs, ys, v[:, 1:], yaw_full[:, 1:]), dim=-1)
+
+
+def action_to_state_and_action(act_scaled: Tensor, cs: Tensor, scaled_input: bool = True,
+                               descaled_output: bool = False) -> Tensor:
+    """models/vae/vae_model.py:100-129 with the (x-mean)/std convention of :131-173
+    (restated: the reference's scale/descale raise on CPU, `get_device()` = -1)."""
+    mean = torch.tensor(NORM_MEAN, dtype=act_scaled.dtype)
+    std = torch.tensor(NORM_STD, dtype=act_scaled.dtype)
+    a = act_scaled * std[4:6] + mean[4:6] if scaled_input else act_scaled
+    st = unicycle_parallel(cs, a)
+    out = torch.cat((st, a), dim=-1)
+    if scaled_input and not descaled_output:
+        out = (out - mean) / std
+    return out
+
+
+def decode(wdec, z: Tensor, cond: Tensor, cs: Tensor, descaled_output: bool = True) -> Tensor:
+    """guide_dm_trainer.py:97-98 -- lstm_dec then convert_action_to_state_and_action -> [B,52,6]."""
+    return action_to_state_and_action(lstm_decode(wdec, z, cond), cs, True, descaled_output)
+
+
+# --------------------------------------------------------------------------- #
+# helpers for tests / bench
+# --------------------------------------------------------------------------- #
+def to_torch(d: dict, dtype=torch.float32) -> Dict[str, Tensor]:
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in d.items()}

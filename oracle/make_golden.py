@@ -1,0 +1,231 @@
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):
+
+    python oracle/make_golden.py
+
+Imports the reference's unmodified files (oracle/_refimport.py), pushes the
+deterministic synthetic weights of `cld_amd.synth` in through
+`load_state_dict`, feeds synthetic inputs / noise, and records the reference's
+outputs.  Fixtures hold only seeds + outputs (KBs); weights, inputs and noise
+are regenerated from the seeds by the tests.  torch CPU fp32, 1 thread
+(recorded in each fixture's `meta`).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cld_amd import synth  # noqa: E402
+from oracle import _refimport  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+W_SEED, IN_SEED, NOISE_SEED = 0, 1, 123
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@contextmanager
+def feed_noise(slabs):
+    """Make the reference's `torch.randn` / `torch.randn_like` calls return the
+    given tensors in order (dm_model.py:110 then :153 once per step)."""
+    it = iter(slabs)
+    o_randn, o_like = torch.randn, torch.randn_like
+
+    def randn(*shape, **kw):
+        z = next(it)
+        shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        assert tuple(z.shape) == shp or z.numel() == int(np.prod(shp)), (z.shape, shp)
+        return z.reshape(shp).clone()
+
+    def randn_like(x, **kw):
+        z = next(it)
+        return z.reshape(x.shape).clone()
+
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+
+
+def build_dm(ref, n_timesteps, affine_jitter):
+    dm = _refimport.quiet(ref.DmModel, ref.algo, None, n_timesteps=n_timesteps).eval()
+    w = synth.make_unet_weights(W_SEED, affine_jitter=affine_jitter)
+    sd = dm.state_dict()
+    for k, v in w.items():
+        assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = T(v)
+    missing = [k for k in sd if k.startswith("model.") and k not in w]
+    assert not missing, missing
+    dm.load_state_dict(sd)
+    return dm
+
+
+def save(name, meta, **arrays):
+    meta = dict(meta, torch=torch.__version__, threads=torch.get_num_threads(),
+                generator="oracle/make_golden.py", source="reference imported from /root/reference")
+    arrays = {k: np.ascontiguousarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v)
+              for k, v in arrays.items()}
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KB  {[ (k, v.shape) for k, v in arrays.items()]}")
+
+
+def main():
+    torch.set_num_threads(1)
+    os.makedirs(GOLD, exist_ok=True)
+    ref = _refimport.load()
+    algo = ref.algo
+
+    # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
+    for n in (100, 10):
+        dm = build_dm(ref, n, False)
+        names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                 "sqrt_one_minus_alphas_cumprod", "posterior_variance",
+                 "posterior_log_variance_clipped", "x_t_cof", "noise_cof"]
+        save(f"schedule_n{n}", {"n_timesteps": n}, **{k: getattr(dm, k) for k in names})
+
+    # ---- (ii) one U-Net forward with intermediate taps ---------------------------
+    for tag, jitter in (("default", False), ("jitter", True)):
+        dm = build_dm(ref, 100, jitter)
+        B = 3
+        x = T(synth.normal(IN_SEED, "unet_x", (B, 52, 4))) * 3.0
+        cond = T(synth.make_inputs(B, IN_SEED)["cond_feat"])
+        t = torch.tensor([99, 50, 0], dtype=torch.long)
+        taps = {}
+        hooks = []
+
+        def hook(name):
+            def f(mod, inp, out):
+                taps[name] = out.detach().clone()
+            return f
+        m = dm.model
+        for name, mod in (("downs.0.1", m.downs[0][1]), ("downs.0.2", m.downs[0][2]),
+                          ("downs.1.1", m.downs[1][1]), ("downs.2.1", m.downs[2][1]),
+                          ("mid_block2", m.mid_block2), ("ups.0.1", m.ups[0][1]),
+                          ("ups.0.2", m.ups[0][2]), ("ups.1.2", m.ups[1][2]),
+                          ("final_conv.0", m.final_conv[0])):
+            hooks.append(mod.register_forward_hook(hook(name)))
+        with torch.no_grad():
+            eps = m(x, {"cond_feat": cond}, t)
+        for h in hooks:
+            h.remove()
+        save(f"unet_forward_{tag}", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "affine_jitter": jitter,
+                                     "x": "3*normal(in_seed,'unet_x')", "t": [99, 50, 0]},
+             eps=eps, **{"tap_" + k.replace(".", "_"): v for k, v in taps.items()})
+
+    # ---- (iii) teacher-forced single steps ---------------------------------------
+    dm = build_dm(ref, 100, True)
+    B = 4
+    x = T(synth.normal(IN_SEED, "step_x", (B, 52, 4)))
+    cond = T(synth.make_inputs(B, IN_SEED)["cond_feat"])
+    z = T(synth.normal(NOISE_SEED, "step_z", (B, 52, 4)))
+    arrays = {}
+    for i in (99, 50, 1, 0):
+        t = torch.full((B,), i, dtype=torch.long)
+        with torch.no_grad(), feed_noise([z]):
+            xn, mean, sigma = dm.x_Tminus1(x, t, {"cond_feat": cond})
+        arrays[f"x_next_t{i}"] = xn
+        arrays[f"mean_t{i}"] = mean
+        arrays[f"sigma_t{i}"] = sigma.reshape(-1)[:1]
+    save("ddpm_step", {"B": B, "w_seed": W_SEED, "affine_jitter": True, "in_seed": IN_SEED,
+                       "noise_seed": NOISE_SEED, "t": [99, 50, 1, 0]}, **arrays)
+
+    # ---- (iv) full sampling chains -----------------------------------------------
+    for n, jitter in ((10, True), (100, False), (100, True)):
+        dm = build_dm(ref, n, jitter)
+        B = 8
+        inp = synth.make_inputs(B, IN_SEED)
+        nz = synth.make_noise(B, n, NOISE_SEED)
+        slabs = [T(nz["x_T"])] + [T(nz["noise"][s]) for s in range(n)]
+        batch = {"history_positions": torch.zeros(B, 31, 2)}
+        with feed_noise(slabs):
+            out = dm(batch, {"cond_feat": T(inp["cond_feat"])}, algo)
+        tag = f"sample_n{n}_{'jitter' if jitter else 'default'}"
+        save(tag, {"B": B, "n_timesteps": n, "w_seed": W_SEED, "affine_jitter": jitter, "in_seed": IN_SEED,
+                   "noise_seed": NOISE_SEED},
+             pred_traj=out["pred_traj"], x1=out["x1"], log_prob_final=out["log_prob_final"])
+        if n == 10:
+            x0_n10 = out["pred_traj"].clone()
+
+    # ---- (v) log_prob (PPO ratio term) at t = 0 and t = 50 ------------------------
+    dm = build_dm(ref, 100, True)
+    B = 4
+    x_t = T(synth.normal(IN_SEED, "lp_xt", (B, 52, 4)))
+    cond = T(synth.make_inputs(B, IN_SEED)["cond_feat"])
+    arrays = {}
+    for i in (0, 50):
+        t = torch.full((B,), i, dtype=torch.long)
+        with torch.no_grad():
+            eps = dm.model(x_t, {"cond_feat": cond}, t)
+            mean, logvar = dm.x_tminus1_mean_var(x_t, eps, t)
+            sig = (0.5 * logvar).exp()
+            # a target one sigma-ish away from the mean so that the t=0 case (sigma 1e-10) stays finite
+            x_tm1 = mean + sig * T(synth.normal(NOISE_SEED, f"lp_z{i}", (B, 52, 4)))
+            lp = dm.log_prob(x_t, x_tm1, {"cond_feat": cond}, t)
+        arrays[f"x_tm1_t{i}"] = x_tm1
+        arrays[f"log_prob_t{i}"] = lp
+    save("log_prob", {"B": B, "w_seed": W_SEED, "affine_jitter": True, "in_seed": IN_SEED,
+                      "noise_seed": NOISE_SEED, "t": [0, 50]}, **arrays)
+
+    # ---- (vi) LSTM decoder + unicycle roll-out ------------------------------------
+    B = 8
+    vae = ref.LSTMVAE(6, 64, 4, 2, device=torch.device("cpu")).eval()
+    wd = synth.make_decoder_weights(W_SEED)
+    sd = vae.state_dict()
+    for k, v in wd.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = T(v)
+    vae.load_state_dict(sd)
+    inp = synth.make_inputs(B, IN_SEED)
+    cond, cs = T(inp["cond_feat"]), T(inp["curr_states"])
+    z_small = T(synth.normal(IN_SEED, "dec_z", (B, 52, 4)))
+    dyn = ref.dynamics.Unicycle("dynamics", max_steer=algo.dynamics["max_steer"],
+                                max_yawvel=algo.dynamics["max_yawvel"], acce_bound=algo.dynamics["acce_bound"])
+    # the reference's own convert_action_to_state_and_action, run on a bare stand-in `self`;
+    # its scale/descale query `Tensor.get_device()` (= -1 on CPU -> error), so that one query is
+    # answered with "cpu" for the duration of the call.  No reference code is altered.
+    fake = types.SimpleNamespace(
+        add_coeffs=np.array(algo.nusc_norm_info.diffuser[0]).astype("float32"),
+        div_coeffs=np.array(algo.nusc_norm_info.diffuser[1]).astype("float32"),
+        default_chosen_inds=[0, 1, 2, 3, 4, 5], dyn=dyn, dt=0.1)
+    fake.scale_traj = types.MethodType(ref.VaeModel.scale_traj, fake)
+    fake.descale_traj = types.MethodType(ref.VaeModel.descale_traj, fake)
+    conv = types.MethodType(ref.VaeModel.convert_action_to_state_and_action, fake)
+    arrays = {}
+    o_gd = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: "cpu"
+    try:
+        with torch.no_grad():
+            for tag, z in (("small", z_small), ("x0n10", x0_n10)):
+                act = vae.lstm_dec(z, cond)
+                arrays[f"act_{tag}"] = act
+                arrays[f"traj_descaled_{tag}"] = conv(act, cs, scaled_input=True, descaled_output=True)
+                arrays[f"traj_scaled_{tag}"] = conv(act, cs, scaled_input=True, descaled_output=False)
+            # a hand-made action sequence that drives every clip of the roll-out:
+            # acc beyond [-10, 8], speed through both v bounds, yaw-rate beyond its bound
+            a_raw = T(synth.normal(IN_SEED, "dyn_act", (B, 52, 2))) * torch.tensor([9.0, 1.5])
+            a_raw[0, :, 0] = 8.5      # accelerates past v = 30
+            a_raw[1, :, 0] = -11.0    # brakes past v = -10
+            arrays["dyn_actions"] = a_raw
+            arrays["dyn_states"] = ref.unicyle_forward_dynamics(dyn, cs, a_raw, 0.1, mode="parallel")
+    finally:
+        torch.Tensor.get_device = o_gd
+    save("decode", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED,
+                    "z_small": "normal(in_seed,'dec_z')", "z_x0n10": "pred_traj of sample_n10_jitter"}, **arrays)
+
+
+if __name__ == "__main__":
+    main()
