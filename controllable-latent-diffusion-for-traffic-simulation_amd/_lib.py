@@ -1,0 +1,72 @@
+"""ctypes binding of libcld_hip.so (C-ABI: include/cld.h).
+
+The product path has NO fallback: if the HIP library is missing or a call
+fails, a `CldError` is raised.  Nothing under `oracle/` is ever imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libcld_hip.so")
+
+
+class CldError(RuntimeError):
+    pass
+
+
+class CldConfig(C.Structure):
+    _fields_ = [
+        ("horizon", C.c_int32), ("latent_dim", C.c_int32), ("cond_dim", C.c_int32), ("base_dim", C.c_int32),
+        ("dim_mults", C.c_int32 * 3), ("hidden", C.c_int32), ("n_timesteps", C.c_int32),
+        ("step_time", C.c_float), ("acce_bound", C.c_float * 2), ("v_bound", C.c_float * 2),
+        ("max_steer", C.c_float), ("max_yawvel", C.c_float),
+        ("norm_mean", C.c_float * 6), ("norm_std", C.c_float * 6),
+    ]
+
+
+_P = C.c_void_p
+# name -> (restype, argtypes); every symbol include/cld.h declares
+SIGNATURES = {
+    "cld_default_config": (None, [C.POINTER(CldConfig)]),
+    "cld_create": (C.c_int, [C.POINTER(CldConfig), C.POINTER(_P)]),
+    "cld_destroy": (C.c_int, [_P]),
+    "cld_last_error": (C.c_char_p, [_P]),
+    "cld_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_size_t]),
+    "cld_finalize": (C.c_int, [_P, _P]),
+    "cld_workspace_bytes": (C.c_size_t, [_P, C.c_int32]),
+    "cld_get_schedule": (C.c_int, [_P, _P, _P, _P]),
+    "cld_unet_forward": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "cld_ddpm_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.c_size_t, _P]),
+    "cld_sample": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
+    "cld_log_prob": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "cld_lstm_decode": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
+    "cld_action_to_state": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "cld_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    "cld_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcld_hip.so (built by `__graft_entry__.build()` / `build.sh`); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CldError(f"{LIB_PATH} not found: build the HIP library first "
+                       f"(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(handle, rc, what):
+    if rc != 0:
+        msg = load().cld_last_error(handle)
+        raise CldError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Build libcld_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+    -o libcld_hip.so csrc/conv_block.hip csrc/misc_kernels.hip csrc/cld_api.hip "$@"
+echo "built $(pwd)/libcld_hip.so"

@@ -1,0 +1,612 @@
+// cld_api.hip -- the C-ABI of libcld_hip (include/cld.h): handle, weight ingestion and
+// re-layout, the per-step launch plan of the denoiser, and the sampling loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cld.h"
+#include "cld_kernels.h"
+
+using namespace cld;
+
+namespace {
+
+constexpr int T = 52, D = 4, COND = 256, TE = 32, NCB = 1792, ACT = 3328;   // ACT floats/agent/buffer
+constexpr int NBUF = 8;
+
+struct BlockDef { const char* name; int cin, cout, L; };
+// the 12 residual blocks in execution order (temporal.py:84-115,148-167)
+const BlockDef kBlocks[12] = {
+    {"model.downs.0.0", 4, 64, 52},   {"model.downs.0.1", 64, 64, 52},
+    {"model.downs.1.0", 64, 128, 26}, {"model.downs.1.1", 128, 128, 26},
+    {"model.downs.2.0", 128, 256, 13}, {"model.downs.2.1", 256, 256, 13},
+    {"model.mid_block1", 256, 256, 13}, {"model.mid_block2", 256, 256, 13},
+    {"model.ups.0.0", 512, 128, 13},  {"model.ups.0.1", 128, 128, 13},
+    {"model.ups.1.0", 256, 64, 26},   {"model.ups.1.1", 64, 64, 26},
+};
+
+struct ConvLayer {
+    ConvGeom g{};
+    float *wfrag = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;
+    int c_out = 0, c1_real = 0, c1_pad = 0, c2 = 0, ly = 0, off0 = 0, orow0 = 0;
+    int cb_off = -1;    // offset into the 1792-wide cond/time bias rows, -1 = none
+};
+
+struct ResBlock { ConvLayer c0, c1, res; bool has_res = false; };
+
+}  // namespace
+
+struct cld_handle_s {
+    cld_config cfg{};
+    std::string err;
+    std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
+    std::map<std::string, size_t> expect;            // name -> numel
+    bool finalized = false, has_decoder = false;
+    std::vector<void*> dev_allocs;
+    // schedule (host, fp32 as in dm_model.py:29-56)
+    std::vector<float> x_t_cof, noise_cof, plvc;
+    // device-side model
+    ResBlock blocks[12];
+    ConvLayer down[2], upT[2][2], final_cb;
+    float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr;
+    DecoderWeights dec{};
+    DynParams dyn{};
+};
+
+namespace {
+
+int fail(cld_handle h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+#define HIPCK(h, expr)                                                                           \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail(h, CLD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+float* upload(cld_handle h, const std::vector<float>& v, hipStream_t s, hipError_t* err) {
+    float* d = nullptr;
+    *err = hipMalloc(reinterpret_cast<void**>(&d), v.size() * sizeof(float));
+    if (*err != hipSuccess) return nullptr;
+    h->dev_allocs.push_back(d);
+    *err = hipMemcpyAsync(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, s);
+    return d;
+}
+
+void add_expect(cld_handle h) {
+    auto& e = h->expect;
+    auto lin = [&](const std::string& p, int o, int i) { e[p + ".weight"] = (size_t)o * i; e[p + ".bias"] = o; };
+    auto conv = [&](const std::string& p, int o, int i, int k) { e[p + ".weight"] = (size_t)o * i * k; e[p + ".bias"] = o; };
+    auto gn = [&](const std::string& p, int c) { e[p + ".weight"] = c; e[p + ".bias"] = c; };
+    lin("model.time_mlp.1", 128, 32);
+    lin("model.time_mlp.3", 32, 128);
+    for (const auto& b : kBlocks) {
+        const std::string p = b.name;
+        lin(p + ".time_mlp.1", b.cout, COND + TE);
+        conv(p + ".blocks.0.block.0", b.cout, b.cin, 5);
+        gn(p + ".blocks.0.block.2", b.cout);
+        conv(p + ".blocks.1.block.0", b.cout, b.cout, 5);
+        gn(p + ".blocks.1.block.2", b.cout);
+        if (b.cin != b.cout) conv(p + ".residual_conv", b.cout, b.cin, 1);
+    }
+    conv("model.downs.0.2.conv", 64, 64, 3);
+    conv("model.downs.1.2.conv", 128, 128, 3);
+    conv("model.ups.0.2.conv", 128, 128, 4);
+    conv("model.ups.1.2.conv", 64, 64, 4);
+    conv("model.final_conv.0.block.0", 64, 64, 5);
+    gn("model.final_conv.0.block.2", 64);
+    conv("model.final_conv.1", 4, 64, 1);
+    // decoder (lstm_vae.py:28-43)
+    e["lstm_dec.lstm.weight_ih_l0"] = 256 * 4;  e["lstm_dec.lstm.weight_hh_l0"] = 256 * 64;
+    e["lstm_dec.lstm.bias_ih_l0"] = 256;        e["lstm_dec.lstm.bias_hh_l0"] = 256;
+    e["lstm_dec.lstm.weight_ih_l1"] = 256 * 64; e["lstm_dec.lstm.weight_hh_l1"] = 256 * 64;
+    e["lstm_dec.lstm.bias_ih_l1"] = 256;        e["lstm_dec.lstm.bias_hh_l1"] = 256;
+    e["lstm_dec.cond2hidden.weight"] = 64 * 256; e["lstm_dec.cond2hidden.bias"] = 64;
+    e["lstm_dec.hid2act.weight"] = 2 * 64;       e["lstm_dec.hid2act.bias"] = 2;
+}
+
+// dm_model.py:29-56 + diffuser_helpers.py:451-462, same op order in fp32
+void build_schedule(cld_handle h) {
+    const int n = h->cfg.n_timesteps;
+    std::vector<double> ac(n + 1);
+    const double s = 0.008;
+    const int steps = n + 1;
+    for (int i = 0; i <= n; ++i) {
+        const double x = (double)steps * (double)i / (double)(steps - 1);      // np.linspace(0, steps, steps)
+        const double c = std::cos(((x / steps) + s) / (1 + s) * M_PI * 0.5);
+        ac[i] = c * c;
+    }
+    const double a0 = ac[0];
+    for (auto& v : ac) v /= a0;
+    std::vector<float> betas(n), alphas(n), acp(n), acp_prev(n);
+    for (int i = 0; i < n; ++i) {
+        double b = 1.0 - ac[i + 1] / ac[i];
+        b = b < 0 ? 0 : (b > 0.999 ? 0.999 : b);
+        betas[i] = (float)b;
+        alphas[i] = 1.0f - betas[i];
+    }
+    float run = 1.0f;
+    for (int i = 0; i < n; ++i) { acp_prev[i] = run; run = run * alphas[i]; acp[i] = run; }
+    acp_prev[0] = 1.0f;
+    h->x_t_cof.resize(n); h->noise_cof.resize(n); h->plvc.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const float pv = betas[i] * (1.0f - acp_prev[i]) / (1.0f - acp[i]);
+        h->plvc[i] = std::log(pv < 1e-20f ? 1e-20f : pv);
+        h->x_t_cof[i] = std::sqrt(1.0f / alphas[i]);
+        h->noise_cof[i] = betas[i] / std::sqrt(alphas[i] - acp[i] * alphas[i]);
+    }
+}
+
+double mish_d(double x) { return x * std::tanh(std::log1p(std::exp(x))); }
+
+// MFMA-fragment weight packing.  Slab (chunk c, tap t, group kg) holds, for every 16-column N tile nt
+// and lane, the 4 values W[co = 16 nt + (lane & 15)][ci = c*KC + 16 kg + 4 (lane >> 4) + s][tap t].
+template <class F>
+std::vector<float> pack_conv_weights(F&& wget, int c_out, int cin_virtual, int ntaps, int kc) {
+    const int nchunk = cin_virtual / kc, nkg = kc / 16, ntn = c_out / 16;
+    std::vector<float> out((size_t)nchunk * ntaps * nkg * ntn * 256);
+    size_t o = 0;
+    for (int c = 0; c < nchunk; ++c)
+        for (int t = 0; t < ntaps; ++t)
+            for (int kg = 0; kg < nkg; ++kg)
+                for (int nt = 0; nt < ntn; ++nt)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s = 0; s < 4; ++s)
+                            out[o++] = wget(16 * nt + (lane & 15), c * kc + 16 * kg + 4 * (lane >> 4) + s, t);
+    return out;
+}
+
+struct Ws {
+    float *xw, *xtmp, *meanb, *cb, *buf[NBUF];
+};
+size_t ws_floats(int b_pad) { return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT); }
+Ws carve(void* ws, int b_pad) {
+    Ws w;
+    float* p = static_cast<float*>(ws);
+    w.xw = p; p += (size_t)b_pad * T * D;
+    w.xtmp = p; p += (size_t)b_pad * T * D;
+    w.meanb = p; p += (size_t)b_pad * T * D;
+    w.cb = p; p += (size_t)b_pad * NCB;
+    for (int i = 0; i < NBUF; ++i) { w.buf[i] = p; p += (size_t)b_pad * ACT; }
+    return w;
+}
+inline int pad16(int b) { return (b + 15) / 16 * 16; }
+
+hipError_t run_conv(const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
+                    const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
+    ConvArgs a{};
+    a.x1 = x1; a.x2 = x2; a.c1_real = l.c1_real; a.c1_pad = l.c1_pad; a.c2 = l.c2;
+    a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
+    if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
+    a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
+    return launch_conv(l.g, a, b_pad, 0, s);
+}
+
+// One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
+// final_conv.0 activations [b_pad,52,64] in w.buf[7].
+hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_pad, hipStream_t s) {
+    const float* tbr = h->tb + (size_t)t_idx * NCB;
+    float* const* b = w.buf;
+    hipError_t e;
+#define RC(...) do { e = run_conv(__VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
+    auto resblock = [&](const ResBlock& rb, const float* in1, const float* in2, float* out) -> hipError_t {
+        const float* r = in1;           // identity residual reads the block input
+        if (rb.has_res) { RC(rb.res, in1, in2, b[0], nullptr); r = b[0]; }
+        RC(rb.c0, in1, in2, b[1], nullptr);
+        RC(rb.c1, b[1], nullptr, out, r);
+        return hipSuccess;
+    };
+#define RB(...) do { e = resblock(__VA_ARGS__); if (e != hipSuccess) return e; } while (0)
+    RB(h->blocks[0], x, nullptr, b[2]);
+    RB(h->blocks[1], b[2], nullptr, b[3]);
+    RC(h->down[0], b[3], nullptr, b[6], nullptr);
+    RB(h->blocks[2], b[6], nullptr, b[2]);
+    RB(h->blocks[3], b[2], nullptr, b[4]);            // skip 128@26
+    RC(h->down[1], b[4], nullptr, b[6], nullptr);
+    RB(h->blocks[4], b[6], nullptr, b[2]);
+    RB(h->blocks[5], b[2], nullptr, b[5]);            // skip 256@13
+    RB(h->blocks[6], b[5], nullptr, b[2]);
+    RB(h->blocks[7], b[2], nullptr, b[3]);
+    RB(h->blocks[8], b[3], b[5], b[2]);               // cat(x, skip) 512@13 -> 128@13
+    RB(h->blocks[9], b[2], nullptr, b[6]);
+    RC(h->upT[0][0], b[6], nullptr, b[3], nullptr);
+    RC(h->upT[0][1], b[6], nullptr, b[3], nullptr);   // 128@26
+    RB(h->blocks[10], b[3], b[4], b[2]);              // cat(x, skip) 256@26 -> 64@26
+    RB(h->blocks[11], b[2], nullptr, b[6]);
+    RC(h->upT[1][0], b[6], nullptr, b[3], nullptr);
+    RC(h->upT[1][1], b[6], nullptr, b[3], nullptr);   // 64@52
+    RC(h->final_cb, b[3], nullptr, b[7], nullptr);
+#undef RB
+#undef RC
+    return hipSuccess;
+}
+
+const std::vector<float>* getw(cld_handle h, const std::string& k) {
+    auto it = h->w.find(k);
+    return it == h->w.end() ? nullptr : &it->second;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* cld_version(void) { return "libcld_hip 0.1.0 gfx950 mfma_f32_16x16x4"; }
+
+void cld_default_config(cld_config* c) {
+    if (!c) return;
+    c->horizon = 52; c->latent_dim = 4; c->cond_dim = 256; c->base_dim = 32;
+    c->dim_mults[0] = 2; c->dim_mults[1] = 4; c->dim_mults[2] = 8;
+    c->hidden = 64; c->n_timesteps = 100; c->step_time = 0.1f;
+    c->acce_bound[0] = -10.f; c->acce_bound[1] = 8.f;
+    c->v_bound[0] = -10.f; c->v_bound[1] = 30.f;
+    c->max_steer = 0.5f; c->max_yawvel = 6.283185307179586f;
+    const float mean[6] = {13.162f, -0.13891f, 5.0223f, -0.0046415f, -0.0080072f, -0.0013546f};
+    const float stdv[6] = {13.0717f, 2.2462f, 3.6187f, 0.2210f, 2.5770f, 0.0840f};
+    for (int i = 0; i < 6; ++i) { c->norm_mean[i] = mean[i]; c->norm_std[i] = stdv[i]; }
+}
+
+int cld_create(const cld_config* cfg, cld_handle* out) {
+    if (!cfg || !out) return CLD_ERR_ARG;
+    *out = nullptr;
+    if (cfg->horizon != 52 || cfg->latent_dim != 4 || cfg->cond_dim != 256 || cfg->base_dim != 32 ||
+        cfg->dim_mults[0] != 2 || cfg->dim_mults[1] != 4 || cfg->dim_mults[2] != 8 || cfg->hidden != 64 ||
+        cfg->n_timesteps < 1 || cfg->n_timesteps > 4096)
+        return CLD_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CLD_ERR_HIP;
+    cld_handle h = new cld_handle_s();
+    h->cfg = *cfg;
+    add_expect(h);
+    build_schedule(h);
+    DynParams& d = h->dyn;
+    d.dt = cfg->step_time; d.acc_lo = cfg->acce_bound[0]; d.acc_hi = cfg->acce_bound[1];
+    d.v_lo = cfg->v_bound[0]; d.v_hi = cfg->v_bound[1]; d.max_steer = cfg->max_steer; d.max_yawvel = cfg->max_yawvel;
+    for (int i = 0; i < 6; ++i) { d.mean[i] = cfg->norm_mean[i]; d.std[i] = cfg->norm_std[i]; }
+    *out = h;
+    return CLD_OK;
+}
+
+int cld_destroy(cld_handle h) {
+    if (!h) return CLD_ERR_ARG;
+    for (void* p : h->dev_allocs) (void)hipFree(p);
+    delete h;
+    return CLD_OK;
+}
+
+const char* cld_last_error(cld_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int cld_load_weight(cld_handle h, const char* name, const float* data, size_t numel) {
+    if (!h || !name || !data) return fail(h, CLD_ERR_ARG, "cld_load_weight: null argument");
+    if (h->finalized) return fail(h, CLD_ERR_STATE, "cld_load_weight: handle already finalized");
+    std::string k = name;
+    for (const char* pre : {"dm.", "vae.", "lstmvae."})
+        if (k.rfind(pre, 0) == 0) k = k.substr(std::strlen(pre));
+    static const char* sched[] = {"betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+                                  "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+                                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                                  "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+                                  "x_t_cof", "noise_cof"};
+    for (const char* sname : sched)
+        if (k == sname) return CLD_OK;     // rebuilt from n_timesteps by cld_create
+    auto it = h->expect.find(k);
+    if (it == h->expect.end()) return fail(h, CLD_ERR_ARG, "cld_load_weight: unknown key '" + k + "'");
+    if (it->second != numel)
+        return fail(h, CLD_ERR_ARG, "cld_load_weight: '" + k + "' expects " + std::to_string(it->second) +
+                                        " values, got " + std::to_string(numel));
+    h->w[k].assign(data, data + numel);
+    return CLD_OK;
+}
+
+int cld_finalize(cld_handle h, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (h->finalized) return fail(h, CLD_ERR_STATE, "cld_finalize: already finalized");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (const auto& kv : h->expect)
+        if (kv.first.rfind("model.", 0) == 0 && !h->w.count(kv.first))
+            return fail(h, CLD_ERR_STATE, "cld_finalize: missing weight '" + kv.first + "'");
+    hipError_t e = hipSuccess;
+#define UP(dst, vec) do { dst = upload(h, vec, s, &e); if (e != hipSuccess) return fail(h, CLD_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); } while (0)
+
+    // ---- conv layers -------------------------------------------------------------------
+    auto make_conv = [&](ConvLayer& l, const std::string& wname, int c_out, int c1_real, int c2, int L_in, int lm,
+                         int stride, int ntaps, const int* tapk, bool transposed, int off0, int orow0, int ostr,
+                         int ly, int epi, const std::string& gn_name, int nwn) -> int {
+        const std::vector<float>& W = *getw(h, wname + ".weight");
+        const int kc = (c1_real < 32 && c2 == 0) ? 16 : 32;
+        const int c1_pad = (c1_real + kc - 1) / kc * kc;
+        const int cin_real = c1_real + c2;
+        const int kw = (int)(W.size() / ((size_t)c_out * cin_real));
+        auto wget = [&](int co, int civ, int t) -> float {
+            int ci;
+            if (civ < c1_pad) { if (civ >= c1_real) return 0.f; ci = civ; }
+            else ci = c1_real + (civ - c1_pad);
+            const int k = tapk[t];
+            return transposed ? W[((size_t)ci * c_out + co) * kw + k]     // ConvTranspose1d [C_in, C_out, k]
+                              : W[((size_t)co * cin_real + ci) * kw + k]; // Conv1d [C_out, C_in, k]
+        };
+        std::vector<float> packed = pack_conv_weights(wget, c_out, c1_pad + c2, ntaps, kc);
+        UP(l.wfrag, packed);
+        UP(l.bias, *getw(h, wname + ".bias"));
+        if (epi == EPI_GN_MISH) {
+            UP(l.gamma, *getw(h, gn_name + ".weight"));
+            UP(l.beta, *getw(h, gn_name + ".bias"));
+        }
+        l.c_out = c_out; l.c1_real = c1_real; l.c1_pad = c1_pad; l.c2 = c2; l.ly = ly; l.off0 = off0; l.orow0 = orow0;
+        l.g = ConvGeom{L_in, lm, stride, ntaps, kc, nwn, epi, c_out / 8, ostr};
+        if (!conv_geom_supported(l.g))
+            return fail(h, CLD_ERR_ARG, "cld_finalize: no kernel instance for layer '" + wname + "'");
+        return CLD_OK;
+    };
+    static const int k5[5] = {0, 1, 2, 3, 4}, k3[3] = {0, 1, 2}, k1[1] = {0};
+    static const int kT_even[2] = {3, 1}, kT_odd[2] = {2, 0};   // out[2j] = x[j-1] W3 + x[j] W1 ; out[2j+1] = x[j] W2 + x[j+1] W0
+    int cb_off = 0, rc;
+    for (int i = 0; i < 12; ++i) {
+        const BlockDef& bd = kBlocks[i];
+        ResBlock& rb = h->blocks[i];
+        const std::string p = bd.name;
+        const bool cat = (i == 8 || i == 10);
+        const int c1 = cat ? bd.cin / 2 : bd.cin, c2 = cat ? bd.cin / 2 : 0;
+        // N tiling: 64 output channels per workgroup, except where that would leave fewer N-tiles than the
+        // other layers of the level (the up path): 32 + a 2-way K split keeps all four waves busy.
+        const int nwn = (i >= 8) ? 2 : 4;
+        if ((rc = make_conv(rb.c0, p + ".blocks.0.block.0", bd.cout, c1, c2, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1, bd.L,
+                            EPI_GN_MISH, p + ".blocks.0.block.2", nwn)) != CLD_OK) return rc;
+        rb.c0.cb_off = cb_off;
+        if ((rc = make_conv(rb.c1, p + ".blocks.1.block.0", bd.cout, bd.cout, 0, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1,
+                            bd.L, EPI_GN_MISH, p + ".blocks.1.block.2", nwn)) != CLD_OK) return rc;
+        rb.has_res = bd.cin != bd.cout;
+        if (rb.has_res)
+            if ((rc = make_conv(rb.res, p + ".residual_conv", bd.cout, c1, c2, bd.L, bd.L, 1, 1, k1, false, 0, 0, 1, bd.L,
+                                EPI_BIAS, "", nwn)) != CLD_OK) return rc;
+        cb_off += bd.cout;
+    }
+    if ((rc = make_conv(h->down[0], "model.downs.0.2.conv", 64, 64, 0, 52, 26, 2, 3, k3, false, -1, 0, 1, 26, EPI_BIAS, "", 2))) return rc;
+    if ((rc = make_conv(h->down[1], "model.downs.1.2.conv", 128, 128, 0, 26, 13, 2, 3, k3, false, -1, 0, 1, 13, EPI_BIAS, "", 2))) return rc;
+    for (int u = 0; u < 2; ++u) {
+        const std::string p = u == 0 ? "model.ups.0.2.conv" : "model.ups.1.2.conv";
+        const int c = u == 0 ? 128 : 64, L = u == 0 ? 13 : 26;
+        if ((rc = make_conv(h->upT[u][0], p, c, c, 0, L, L, 1, 2, kT_even, true, -1, 0, 2, 2 * L, EPI_BIAS, "", 4))) return rc;
+        if ((rc = make_conv(h->upT[u][1], p, c, c, 0, L, L, 1, 2, kT_odd, true, 0, 1, 2, 2 * L, EPI_BIAS, "", 4))) return rc;
+    }
+    if ((rc = make_conv(h->final_cb, "model.final_conv.0.block.0", 64, 64, 0, 52, 52, 1, 5, k5, false, -2, 0, 1, 52,
+                        EPI_GN_MISH, "model.final_conv.0.block.2", 4))) return rc;
+
+    // ---- cond half of every block's time_mlp Linear, concatenated: wc [1792][256], bias [1792] ----
+    // ---- time half folded with the timestep embedding into a table tb [n_timesteps][1792]       ----
+    {
+        std::vector<float> wc((size_t)NCB * COND), bb(NCB);
+        std::vector<float> wt((size_t)NCB * TE);
+        int off = 0;
+        for (const auto& bd : kBlocks) {
+            const std::vector<float>& W = *getw(h, std::string(bd.name) + ".time_mlp.1.weight");   // [cout, 288]: [0:32] time, [32:288] cond
+            const std::vector<float>& Bv = *getw(h, std::string(bd.name) + ".time_mlp.1.bias");
+            for (int n = 0; n < bd.cout; ++n) {
+                for (int k = 0; k < TE; ++k) wt[(size_t)(off + n) * TE + k] = W[(size_t)n * (TE + COND) + k];
+                for (int k = 0; k < COND; ++k) wc[(size_t)(off + n) * COND + k] = W[(size_t)n * (TE + COND) + TE + k];
+                bb[off + n] = Bv[n];
+            }
+            off += bd.cout;
+        }
+        UP(h->wc, wc);
+        UP(h->cbias_b, bb);
+        const std::vector<float>& W1 = *getw(h, "model.time_mlp.1.weight");   // [128,32]
+        const std::vector<float>& B1 = *getw(h, "model.time_mlp.1.bias");
+        const std::vector<float>& W3 = *getw(h, "model.time_mlp.3.weight");   // [32,128]
+        const std::vector<float>& B3 = *getw(h, "model.time_mlp.3.bias");
+        const int n = h->cfg.n_timesteps;
+        std::vector<float> tb((size_t)n * NCB);
+        const int half = TE / 2;
+        const float negc = (float)(-(std::log(10000.0) / (half - 1)));
+        for (int t = 0; t < n; ++t) {
+            float emb[TE];
+            for (int k = 0; k < half; ++k) {              // diffuser_helpers.py:25-32, fp32 like the reference
+                const float wk = std::exp((float)k * negc);
+                const float ph = (float)t * wk;
+                emb[k] = std::sin(ph);
+                emb[half + k] = std::cos(ph);
+            }
+            double h1[128], te[TE];
+            for (int j = 0; j < 128; ++j) {
+                double a = B1[j];
+                for (int k = 0; k < TE; ++k) a += (double)W1[j * TE + k] * emb[k];
+                h1[j] = mish_d((double)(float)a);
+            }
+            for (int j = 0; j < TE; ++j) {
+                double a = B3[j];
+                for (int k = 0; k < 128; ++k) a += (double)W3[j * 128 + k] * (double)(float)h1[k];
+                te[j] = mish_d((double)(float)a);          // the block's Mish on the [t_emb | cond] vector
+            }
+            for (int nn = 0; nn < NCB; ++nn) {
+                double a = 0;
+                for (int k = 0; k < TE; ++k) a += (double)wt[(size_t)nn * TE + k] * (double)(float)te[k];
+                tb[(size_t)t * NCB + nn] = (float)a;
+            }
+        }
+        UP(h->tb, tb);
+    }
+    UP(h->head_w, *getw(h, "model.final_conv.1.weight"));
+    UP(h->head_b, *getw(h, "model.final_conv.1.bias"));
+
+    // ---- decoder (optional) ---------------------------------------------------------------
+    h->has_decoder = true;
+    for (const auto& kv : h->expect)
+        if (kv.first.rfind("lstm_dec.", 0) == 0 && !h->w.count(kv.first)) h->has_decoder = false;
+    if (h->has_decoder) {
+        float* tmp;
+        UP(tmp, *getw(h, "lstm_dec.lstm.weight_ih_l0")); h->dec.w_ih0 = tmp;
+        UP(tmp, *getw(h, "lstm_dec.lstm.weight_hh_l0")); h->dec.w_hh0 = tmp;
+        UP(tmp, *getw(h, "lstm_dec.lstm.weight_ih_l1")); h->dec.w_ih1 = tmp;
+        UP(tmp, *getw(h, "lstm_dec.lstm.weight_hh_l1")); h->dec.w_hh1 = tmp;
+        std::vector<float> b0(256), b1(256);
+        for (int i = 0; i < 256; ++i) {
+            b0[i] = (*getw(h, "lstm_dec.lstm.bias_ih_l0"))[i] + (*getw(h, "lstm_dec.lstm.bias_hh_l0"))[i];
+            b1[i] = (*getw(h, "lstm_dec.lstm.bias_ih_l1"))[i] + (*getw(h, "lstm_dec.lstm.bias_hh_l1"))[i];
+        }
+        UP(tmp, b0); h->dec.b0 = tmp;
+        UP(tmp, b1); h->dec.b1 = tmp;
+        UP(tmp, *getw(h, "lstm_dec.cond2hidden.weight")); h->dec.w_c2h = tmp;
+        UP(tmp, *getw(h, "lstm_dec.cond2hidden.bias")); h->dec.b_c2h = tmp;
+        UP(tmp, *getw(h, "lstm_dec.hid2act.weight")); h->dec.w_h2a = tmp;
+        UP(tmp, *getw(h, "lstm_dec.hid2act.bias")); h->dec.b_h2a = tmp;
+    }
+#undef UP
+    HIPCK(h, hipStreamSynchronize(s));     // host staging vectors die with this scope
+    h->w.clear();
+    h->finalized = true;
+    return CLD_OK;
+}
+
+size_t cld_workspace_bytes(cld_handle h, int32_t B) {
+    if (!h || B < 1) return 0;
+    return ws_floats(pad16(B)) * sizeof(float);
+}
+
+int cld_get_schedule(cld_handle h, float* x_t_cof, float* noise_cof, float* post_log_var) {
+    if (!h) return CLD_ERR_ARG;
+    const size_t n = h->x_t_cof.size() * sizeof(float);
+    if (x_t_cof) std::memcpy(x_t_cof, h->x_t_cof.data(), n);
+    if (noise_cof) std::memcpy(noise_cof, h->noise_cof.data(), n);
+    if (post_log_var) std::memcpy(post_log_var, h->plvc.data(), n);
+    return CLD_OK;
+}
+
+static int check_common(cld_handle h, const char* fn, int B, int t_idx, const void* ws, size_t ws_bytes) {
+    if (!h) return CLD_ERR_ARG;
+    if (!h->finalized) return fail(h, CLD_ERR_STATE, std::string(fn) + ": weights not finalized");
+    if (B < 1) return fail(h, CLD_ERR_ARG, std::string(fn) + ": B < 1");
+    if (t_idx < 0 || t_idx >= h->cfg.n_timesteps) return fail(h, CLD_ERR_ARG, std::string(fn) + ": timestep out of range");
+    if (!ws || ws_bytes < cld_workspace_bytes(h, B)) return fail(h, CLD_ERR_WORKSPACE, std::string(fn) + ": workspace too small");
+    if (reinterpret_cast<uintptr_t>(ws) % 16) return fail(h, CLD_ERR_ARG, std::string(fn) + ": workspace must be 16-byte aligned");
+    return CLD_OK;
+}
+
+int cld_unet_forward(cld_handle h, const float* x, const float* cond, int32_t t_idx, float* eps, int32_t B,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_unet_forward", B, t_idx, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x || !cond || !eps) return fail(h, CLD_ERR_ARG, "cld_unet_forward: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(B);
+    Ws w = carve(workspace, bp);
+    HIPCK(h, launch_pack_latent(x, w.xw, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    HIPCK(h, run_unet(h, w, w.xw, t_idx, bp, s));
+    HeadArgs a{};
+    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
+    HIPCK(h, launch_head(a, s));
+    return CLD_OK;
+}
+
+int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx, const float* z, float* x_next,
+                  float* mean, float* sigma_host, int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_ddpm_step", B, t_idx, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x || !cond || (!z && x_next && t_idx != 0)) return fail(h, CLD_ERR_ARG, "cld_ddpm_step: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(B);
+    Ws w = carve(workspace, bp);
+    const float sigma = std::exp(0.5f * h->plvc[t_idx]);
+    if (sigma_host) *sigma_host = sigma;
+    HIPCK(h, launch_pack_latent(x, w.xw, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    HIPCK(h, run_unet(h, w, w.xw, t_idx, bp, s));
+    HeadArgs a{};
+    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.z = z; a.B = B; a.b_pad = bp;
+    a.mean_out = w.meanb; a.x_out = w.xtmp;
+    a.xc = h->x_t_cof[t_idx]; a.nc = h->noise_cof[t_idx];
+    a.sg = (t_idx == 0) ? 0.f : sigma;       // nonzero_mask, dm_model.py:151
+    HIPCK(h, launch_head(a, s));
+    if (x_next) HIPCK(h, launch_unpack(w.xtmp, x_next, B, s));
+    if (mean) HIPCK(h, launch_unpack(w.meanb, mean, B, s));
+    return CLD_OK;
+}
+
+int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* cond, int32_t steps, float* x0,
+               float* x1, float* logp, int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_sample", B, 0, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x_T || !cond) return fail(h, CLD_ERR_ARG, "cld_sample: null pointer");
+    if (steps != h->cfg.n_timesteps)
+        return fail(h, CLD_ERR_ARG, "cld_sample: steps must equal n_timesteps (the reference sampler has stride 1)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(B);
+    Ws w = carve(workspace, bp);
+    HIPCK(h, launch_pack_latent(x_T, w.xw, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    for (int it = 0; it < steps; ++it) {
+        const int i = steps - 1 - it;
+        HIPCK(h, run_unet(h, w, w.xw, i, bp, s));
+        const float sigma = std::exp(0.5f * h->plvc[i]);
+        HeadArgs a{};
+        a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
+        a.z = noise ? noise + (size_t)it * B * T * D : nullptr;
+        a.seed = seed; a.step_salt = (unsigned long long)it;
+        a.x_out = w.xw;                                   // in place: each thread rewrites the row it read
+        a.mean_out = (i == 0) ? w.meanb : nullptr;
+        a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
+        a.sg = (i == 0) ? 0.f : sigma;
+        HIPCK(h, launch_head(a, s));
+        if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
+        if (i == 0) {
+            if (x0) HIPCK(h, launch_unpack(w.xw, x0, B, s));
+            if (logp) HIPCK(h, launch_logprob(w.xw, w.meanb, sigma, logp, B, s));
+        }
+    }
+    return CLD_OK;
+}
+
+int cld_log_prob(cld_handle h, const float* x_t, const float* x_tm1, const float* cond, int32_t t_idx, float* out,
+                 int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_log_prob", M, t_idx, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x_t || !x_tm1 || !cond || !out) return fail(h, CLD_ERR_ARG, "cld_log_prob: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(M);
+    Ws w = carve(workspace, bp);
+    HIPCK(h, launch_pack_latent(x_t, w.xw, M, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, M, bp, NCB, s));
+    HIPCK(h, run_unet(h, w, w.xw, t_idx, bp, s));
+    HeadArgs a{};
+    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = M; a.b_pad = bp;
+    a.mean_out = w.meanb; a.xc = h->x_t_cof[t_idx]; a.nc = h->noise_cof[t_idx];
+    HIPCK(h, launch_head(a, s));
+    HIPCK(h, launch_logprob(x_tm1, w.meanb, std::exp(0.5f * h->plvc[t_idx]), out, M, s));
+    return CLD_OK;
+}
+
+int cld_lstm_decode(cld_handle h, const float* z, const float* cond, float* act, int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!h->finalized || !h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_lstm_decode: decoder weights not loaded");
+    if (!z || !cond || !act || B < 1) return fail(h, CLD_ERR_ARG, "cld_lstm_decode: bad argument");
+    HIPCK(h, launch_decode(h->dec, h->dyn, z, cond, nullptr, act, nullptr, B, 1, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+int cld_action_to_state(cld_handle h, const float* act, const float* curr_states, float* traj, int32_t B,
+                        int32_t scaled_input, int32_t descaled_output, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!act || !curr_states || !traj || B < 1) return fail(h, CLD_ERR_ARG, "cld_action_to_state: bad argument");
+    HIPCK(h, launch_action_to_state(h->dyn, act, curr_states, traj, B, scaled_input, descaled_output,
+                                    static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+int cld_decode(cld_handle h, const float* z, const float* cond, const float* curr_states, float* traj, float* act_out,
+               int32_t B, int32_t descaled_output, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!h->finalized || !h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_decode: decoder weights not loaded");
+    if (!z || !cond || !curr_states || !traj || B < 1) return fail(h, CLD_ERR_ARG, "cld_decode: bad argument");
+    HIPCK(h, launch_decode(h->dec, h->dyn, z, cond, curr_states, act_out, traj, B, descaled_output,
+                           static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+}  // extern "C"

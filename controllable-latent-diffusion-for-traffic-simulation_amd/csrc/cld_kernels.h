@@ -1,0 +1,105 @@
+// Internal kernel interfaces of libcld_hip (not part of the public C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cld {
+
+// ---------------------------------------------------------------------------
+// Activation layout in HBM: channels-last [B_pad, L, C] fp32, B_pad = B rounded
+// up to 16 agents.  All three U-Net resolutions hold 3,328 floats per agent at
+// their widest (64x52 = 128x26 = 256x13).
+//
+// One conv workgroup owns MT = 208 output rows (16 / 8 / 4 whole agents at
+// L = 13 / 26 / 52) x NT output channels and runs the implicit GEMM
+//     out[r, n] = sum_{tap, ci} X[in_row(r) + tap, ci] * W[tap][ci][n]
+// on v_mfma_f32_16x16x4_f32, 13 M-tiles x 1 N-tile per wave.
+// ---------------------------------------------------------------------------
+constexpr int MT = 208;
+constexpr int NMT = 13;
+
+enum { EPI_BIAS = 0, EPI_GN_MISH = 1 };
+
+struct ConvArgs {
+    // sources: virtual input channels = [x1 (c1_pad, real c1_real) | x2 (c2)]
+    const float* x1;
+    const float* x2;
+    int c1_real;     // channels actually present in x1 (row stride of x1)
+    int c1_pad;      // c1_real rounded up to the K-chunk; chunks beyond c1_real read zeros
+    int c2;          // channels of x2 (0 if none)
+    const float* wfrag;   // MFMA-fragment-ordered weights (see pack_conv_weights)
+    const float* bias;    // [c_out] conv bias
+    const float* gamma;   // [c_out] GroupNorm weight (EPI_GN_MISH)
+    const float* beta;    // [c_out] GroupNorm bias
+    const float* cbias;   // per-agent vector added after Mish: cbias[b*cb_stride + n] (or null)
+    int cb_stride;
+    const float* tbias;   // per-step vector added after Mish: tbias[n] (or null)
+    const float* res;     // residual tensor, same layout as y (or null)
+    float* y;             // output [B_pad, ly, c_out]
+    int c_out;
+    int ly;               // rows per agent of the OUTPUT tensor
+    int off0;             // input row of tap 0 relative to STRIDE*j
+    int orow0;            // output row = OSTR*j + orow0
+};
+
+// A launcher picks the template instance from the geometry; returns hipError_t.
+struct ConvGeom {
+    int l_in;     // input rows per agent
+    int lm;       // GEMM rows per agent (output positions computed per agent)
+    int stride;   // input row step per output position
+    int ntaps;
+    int kc;       // K chunk (channels staged per step): 16 or 32
+    int nwn;      // N-tiles (16 cols) per workgroup: 4 (KS=1) or 2 (KS=2)
+    int epi;
+    int gs;       // GroupNorm group size (channels) = c_out / 8
+    int ostr;     // output row stride (2 for the transposed conv halves)
+};
+hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, int grid_z_index, hipStream_t s);
+bool conv_geom_supported(const ConvGeom& g);
+
+// ---------------------------------------------------------------------------
+// small kernels (misc_kernels.hip)
+// ---------------------------------------------------------------------------
+// x [B,52,4] -> xw [B_pad,52,4] (rows >= B zero-filled)
+hipError_t launch_pack_latent(const float* x, float* xw, int B, int b_pad, hipStream_t s);
+// cb[b, n] = bias[n] + sum_k mish(cond[b,k]) * wc[n,k]   (b < B; pad rows = 0) ; wc is [ncb][256]
+hipError_t launch_cond_bias(const float* cond, const float* wc, const float* bias, float* cb,
+                            int B, int b_pad, int ncb, hipStream_t s);
+// head: eps = W f + b (64 -> 4); mean = xc*x - nc*eps; x' = mean + sg*z
+struct HeadArgs {
+    const float* f;      // [B_pad,52,64]
+    const float* w;      // [4,64]
+    const float* b;      // [4]
+    const float* x;      // [B_pad,52,4] current latent
+    const float* z;      // [B,52,4] noise or null
+    float* eps_out;      // [B,52,4] or null
+    float* mean_out;     // [B_pad,52,4] or null
+    float* x_out;        // [B_pad,52,4] or null (may alias x)
+    float xc, nc, sg;
+    unsigned long long seed;   // on-device RNG (z == null and sg != 0)
+    unsigned long long step_salt;
+    int B, b_pad;
+};
+hipError_t launch_head(const HeadArgs& a, hipStream_t s);
+// out[b] = mean_{t,d} log N(xq[b]; mean[b], sigma)
+hipError_t launch_logprob(const float* xq, const float* mean, float sigma, float* out, int B, hipStream_t s);
+// copy [B,52,4] rows out of a padded buffer
+hipError_t launch_unpack(const float* xw, float* x, int B, hipStream_t s);
+
+struct DecoderWeights {   // device pointers, reference layouts
+    const float *w_ih0, *w_hh0, *b0;   // [256,4] [256,64] [256] (b_ih + b_hh)
+    const float *w_ih1, *w_hh1, *b1;   // [256,64] [256,64] [256]
+    const float *w_c2h, *b_c2h;        // [64,256] [64]
+    const float *w_h2a, *b_h2a;        // [2,64] [2]
+};
+struct DynParams {
+    float dt, acc_lo, acc_hi, v_lo, v_hi, max_steer, max_yawvel;
+    float mean[6], std[6];
+};
+// z [B,52,4], cond [B,256] -> act [B,52,2] (optional) ; if cs != null also traj [B,52,6]
+hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond,
+                         const float* cs, float* act, float* traj, int B, int descaled_output, hipStream_t s);
+hipError_t launch_action_to_state(const DynParams& d, const float* act, const float* cs, float* traj,
+                                  int B, int scaled_input, int descaled_output, hipStream_t s);
+
+}  // namespace cld

@@ -1,0 +1,307 @@
+// misc_kernels.hip -- the small kernels around the conv blocks:
+//   latent pack/unpack, per-sample cond-bias GEMV, the U-Net head (final 1x1 conv fused
+//   with the DDPM update, reference models/dm/dm_model.py:144-163), log-prob
+//   (dm_model.py:130-132,165-174), the LSTM-VAE decoder (models/vae/lstm_vae.py:28-52)
+//   and the unicycle roll-out (src/tbsim/models/diffuser_helpers.py:541-639, 'parallel').
+#include "cld_kernels.h"
+
+namespace cld {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float mish_g(float x) {
+    const float e = expf(fminf(x, 30.0f));
+    const float n = e * (e + 2.0f);
+    return x * (n / (n + 2.0f));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------
+__global__ void pack_latent_kernel(const float* __restrict__ x, float* __restrict__ xw, int nreal, int ntot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one float4 = one (b, l) row
+    if (i >= ntot) return;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (i < nreal) v = reinterpret_cast<const v4f*>(x)[i];
+    reinterpret_cast<v4f*>(xw)[i] = v;
+}
+hipError_t launch_pack_latent(const float* x, float* xw, int B, int b_pad, hipStream_t s) {
+    const int ntot = b_pad * 52, nreal = B * 52;
+    hipLaunchKernelGGL(pack_latent_kernel, dim3((ntot + 255) / 256), dim3(256), 0, s, x, xw, nreal, ntot);
+    return hipGetLastError();
+}
+hipError_t launch_unpack(const float* xw, float* x, int B, hipStream_t s) {
+    return hipMemcpyAsync(x, xw, sizeof(float) * (size_t)B * 52 * 4, hipMemcpyDeviceToDevice, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// cb[b, n] = bias[n] + sum_k mish(cond[b, k]) * wc[n, k]       (temporal.py:21-25,146: the cond half of
+// every block's Linear(Mish([t_emb | cond])) is constant over the denoising loop, so it is computed once
+// per sample).  One workgroup = 8 agents x 256 outputs; mish(cond) rows live in LDS.
+__global__ __launch_bounds__(256) void cond_bias_kernel(const float* __restrict__ cond, const float* __restrict__ wc,
+                                                       const float* __restrict__ bias, float* __restrict__ cb,
+                                                       int B, int ncb) {
+    __shared__ float mc[8][256];
+    const int b0 = blockIdx.x * 8;
+    const int tid = threadIdx.x;
+    for (int a = 0; a < 8; ++a) {
+        const int b = b0 + a;
+        mc[a][tid] = (b < B) ? mish_g(cond[(size_t)b * 256 + tid]) : 0.f;
+    }
+    __syncthreads();
+    const int n = blockIdx.y * 256 + tid;
+    if (n >= ncb) return;
+    float acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) acc[a] = 0.f;
+    const v4f* w4 = reinterpret_cast<const v4f*>(wc + (size_t)n * 256);
+    for (int k4 = 0; k4 < 64; ++k4) {
+        const v4f w = w4[k4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const v4f m = *reinterpret_cast<const v4f*>(&mc[a][k4 * 4]);
+            acc[a] = fmaf(m[0], w[0], acc[a]);
+            acc[a] = fmaf(m[1], w[1], acc[a]);
+            acc[a] = fmaf(m[2], w[2], acc[a]);
+            acc[a] = fmaf(m[3], w[3], acc[a]);
+        }
+    }
+    const float bn = bias[n];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int b = b0 + a;
+        cb[(size_t)b * ncb + n] = (b < B) ? acc[a] + bn : 0.f;
+    }
+}
+hipError_t launch_cond_bias(const float* cond, const float* wc, const float* bias, float* cb, int B, int b_pad,
+                            int ncb, hipStream_t s) {
+    hipLaunchKernelGGL(cond_bias_kernel, dim3(b_pad / 8, (ncb + 255) / 256), dim3(256), 0, s, cond, wc, bias, cb, B, ncb);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// counter-based N(0,1) for throughput runs without caller noise (splitmix64 -> Box-Muller)
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long bits) {
+    return ((float)(bits >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// head: eps = W f + b (final_conv.1, temporal.py:119) ; mean = xc*x - nc*eps ; x' = mean + sg*z
+// one thread per (b, l) row: reads 64 channels (256 B), writes 4 values.
+__global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+    __shared__ float w[4][64];
+    __shared__ float bb[4];
+    const int tid = threadIdx.x;
+    w[tid >> 6][tid & 63] = a.w[tid];
+    if (tid < 4) bb[tid] = a.b[tid];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + tid;
+    if (row >= a.b_pad * 52) return;
+    const v4f* f4 = reinterpret_cast<const v4f*>(a.f + (size_t)row * 64);
+    float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const v4f f = f4[k4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            e[d] = fmaf(f[0], w[d][4 * k4 + 0], e[d]);
+            e[d] = fmaf(f[1], w[d][4 * k4 + 1], e[d]);
+            e[d] = fmaf(f[2], w[d][4 * k4 + 2], e[d]);
+            e[d] = fmaf(f[3], w[d][4 * k4 + 3], e[d]);
+        }
+    }
+    const bool real = row < a.B * 52;
+    v4f eps;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) eps[d] = e[d] + bb[d];
+    if (a.eps_out && real) reinterpret_cast<v4f*>(a.eps_out)[row] = eps;
+    if (!a.mean_out && !a.x_out) return;
+    const v4f x = reinterpret_cast<const v4f*>(a.x)[row];
+    v4f mean;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) mean[d] = a.xc * x[d] - a.nc * eps[d];
+    if (a.mean_out) reinterpret_cast<v4f*>(a.mean_out)[row] = mean;
+    if (a.x_out) {
+        v4f z = {0.f, 0.f, 0.f, 0.f};
+        if (a.sg != 0.f && real) {
+            if (a.z) {
+                z = reinterpret_cast<const v4f*>(a.z)[row];
+            } else {
+                const unsigned long long k = splitmix64(a.seed ^ splitmix64(a.step_salt * 0x100000000ull + (unsigned)row));
+                const unsigned long long r0 = splitmix64(k), r1 = splitmix64(k + 1), r2 = splitmix64(k + 2), r3 = splitmix64(k + 3);
+                const float m0 = sqrtf(-2.0f * logf(u01(r0))), m1 = sqrtf(-2.0f * logf(u01(r2)));
+                float s0, c0, s1, c1;
+                sincosf(6.283185307179586f * u01(r1), &s0, &c0);
+                sincosf(6.283185307179586f * u01(r3), &s1, &c1);
+                z = v4f{m0 * c0, m0 * s0, m1 * c1, m1 * s1};
+            }
+        }
+        v4f xn;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) xn[d] = mean[d] + a.sg * z[d];
+        reinterpret_cast<v4f*>(a.x_out)[row] = xn;
+    }
+}
+hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(head_kernel, dim3((a.b_pad * 52 + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// out[b] = mean over (52 x 4) of Normal(mean, sigma).log_prob(xq)
+//        = -(xq-mean)^2 / (2 sigma^2) - log(sigma) - log(sqrt(2 pi))        (torch.distributions.Normal)
+__global__ __launch_bounds__(64) void logprob_kernel(const float* __restrict__ xq, const float* __restrict__ mean,
+                                                     float sigma, float* __restrict__ out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float var2 = 2.0f * sigma * sigma;
+    const float lc = logf(sigma) + 0.9189385332046727f;
+    float s = 0.f;
+    for (int i = lane; i < 208; i += 64) {
+        const float d = xq[(size_t)b * 208 + i] - mean[(size_t)b * 208 + i];
+        s += -(d * d) / var2 - lc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[b] = s * (1.0f / 208.0f);
+}
+hipError_t launch_logprob(const float* xq, const float* mean, float sigma, float* out, int B, hipStream_t s) {
+    hipLaunchKernelGGL(logprob_kernel, dim3(B), dim3(64), 0, s, xq, mean, sigma, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// unicycle roll-out of one agent, sequential over 52 steps (the reference's tril/bmm form is an
+// O(T^2) way of writing these inclusive prefix sums; v is clipped AFTER the sum, 'parallel' mode).
+__device__ void rollout_agent(const DynParams& d, const float* act /*[52][2] scaled or raw*/, const float* cs,
+                              float* traj /*[52][6]*/, bool scaled_input, bool descaled_output) {
+    float v_raw = cs[2], v_prev = fminf(fmaxf(cs[2], d.v_lo), d.v_hi);
+    float yaw = cs[3], x = cs[0], y = cs[1];
+    for (int t = 0; t < 52; ++t) {
+        float acc = act[2 * t], yr = act[2 * t + 1];
+        if (scaled_input) { acc = acc * d.std[4] + d.mean[4]; yr = yr * d.std[5] + d.mean[5]; }
+        const float accc = fminf(fmaxf(acc, d.acc_lo), d.acc_hi);
+        v_raw += accc * d.dt;
+        const float v = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
+        const float av = fabsf(v_prev);
+        const float yb = fmaxf(fminf(d.max_steer * av, d.max_yawvel / fmaxf(av, 0.1f)), 0.1f);
+        const float yrc = fmaxf(fminf(yr, yb), -yb);
+        const float vavg = 0.5f * (v_prev + v);       // mat2 rows: 0.5*(v_{k-1} + v_k)
+        x += vavg * cosf(yaw) * d.dt;
+        y += vavg * sinf(yaw) * d.dt;
+        yaw += yrc * d.dt;
+        float o[6] = {x, y, v, yaw, acc, yr};
+        if (scaled_input && !descaled_output) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = (o[k] - d.mean[k]) / d.std[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) traj[6 * t + k] = o[k];
+        v_prev = v;
+    }
+}
+
+__global__ void action_to_state_kernel(const DynParams d, const float* __restrict__ act, const float* __restrict__ cs,
+                                       float* __restrict__ traj, int B, int scaled_input, int descaled_output) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    rollout_agent(d, act + (size_t)b * 104, cs + (size_t)b * 4, traj + (size_t)b * 312, scaled_input != 0,
+                  descaled_output != 0);
+}
+hipError_t launch_action_to_state(const DynParams& d, const float* act, const float* cs, float* traj, int B,
+                                  int scaled_input, int descaled_output, hipStream_t s) {
+    hipLaunchKernelGGL(action_to_state_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d, act, cs, traj, B, scaled_input,
+                       descaled_output);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// LSTM decoder: one 256-thread workgroup per agent slot, thread r owns gate row r (PyTorch row order
+// i, f, g, o) of both layers with its weights resident in registers (4 + 64 + 64 + 64 floats);
+// h / c state lives in LDS; 52 sequential steps (lstm_vae.py:44-52: h0 = cond2hidden(cond) for both
+// layers, c0 = 0).  Workgroups stride over agents.
+__global__ __launch_bounds__(256) void decode_kernel(const DecoderWeights w, const DynParams d,
+                                                     const float* __restrict__ z, const float* __restrict__ cond,
+                                                     const float* __restrict__ cs, float* __restrict__ act_out,
+                                                     float* __restrict__ traj, int B, int descaled_output) {
+    __shared__ __attribute__((aligned(16))) float h0[64], h1[64], c0[64], c1[64], gates[256], zin[208], act[104];
+    __shared__ __attribute__((aligned(16))) float condm[256];
+    const int r = threadIdx.x;
+    float wi0[4], wh0[64], wi1[64], wh1[64];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wi0[k] = w.w_ih0[r * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        wh0[k] = w.w_hh0[r * 64 + k];
+        wi1[k] = w.w_ih1[r * 64 + k];
+        wh1[k] = w.w_hh1[r * 64 + k];
+    }
+    const float bias0 = w.b0[r], bias1 = w.b1[r];
+    const int gate = r >> 6, u = r & 63;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        condm[r] = cond[(size_t)b * 256 + r];
+        if (r < 208) zin[r] = z[(size_t)b * 208 + r];
+        __syncthreads();
+        if (r < 64) {   // h0 = cond2hidden(cond)
+            float s = w.b_c2h[r];
+            const float* wr = w.w_c2h + r * 256;
+            for (int k = 0; k < 256; ++k) s = fmaf(condm[k], wr[k], s);
+            h0[r] = s; h1[r] = s; c0[r] = 0.f; c1[r] = 0.f;
+        }
+        __syncthreads();
+        for (int t = 0; t < 52; ++t) {
+            // ---- layer 0 ----
+            float g = bias0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g = fmaf(zin[4 * t + k], wi0[k], g);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g = fmaf(h0[k], wh0[k], g);
+            gates[r] = (gate == 2) ? tanhf(g) : sigmoid_f(g);
+            __syncthreads();
+            if (r < 64) {
+                const float c = gates[64 + r] * c0[r] + gates[r] * gates[128 + r];
+                c0[r] = c;
+                h0[r] = gates[192 + r] * tanhf(c);
+            }
+            __syncthreads();
+            // ---- layer 1 ----
+            g = bias1;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g = fmaf(h0[k], wi1[k], g);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g = fmaf(h1[k], wh1[k], g);
+            gates[r] = (gate == 2) ? tanhf(g) : sigmoid_f(g);
+            __syncthreads();
+            if (r < 64) {
+                const float c = gates[64 + r] * c1[r] + gates[r] * gates[128 + r];
+                c1[r] = c;
+                h1[r] = gates[192 + r] * tanhf(c);
+            }
+            __syncthreads();
+            if (r < 2) {   // hid2act
+                float s = w.b_h2a[r];
+                const float* wr = w.w_h2a + r * 64;
+                for (int k = 0; k < 64; ++k) s = fmaf(h1[k], wr[k], s);
+                act[2 * t + r] = s;
+            }
+        }
+        __syncthreads();
+        if (act_out && r < 104) act_out[(size_t)b * 104 + r] = act[r];
+        if (traj && r == 0) rollout_agent(d, act, cs + (size_t)b * 4, traj + (size_t)b * 312, true, descaled_output != 0);
+        __syncthreads();
+        (void)u;
+    }
+}
+hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond, const float* cs,
+                         float* act, float* traj, int B, int descaled_output, hipStream_t s) {
+    const int grid = B < 2048 ? B : 2048;
+    hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, s, w, d, z, cond, cs, act, cs ? traj : nullptr, B,
+                       descaled_output);
+    return hipGetLastError();
+}
+
+}  // namespace cld

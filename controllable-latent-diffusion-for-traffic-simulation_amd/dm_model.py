@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference `DmModel` call surface over the HIP engine.
+
+Same method names, argument meaning and returned dict keys as
+`/root/reference/models/dm/dm_model.py:15-174` (forward / sample_traj /
+x_Tminus1 / x_tminus1_mean_var / log_prob, and `.model(x, aux_info, t)` for
+`TemporalMapUnet.forward`, `src/tbsim/models/temporal.py:122-180`), so the
+callers in `src/trainers/guide_dm_trainer.py:87,164,189,207` work unchanged.
+Differences, all additive: `noise=` lets the caller supply the Gaussian draws
+(the reference draws them with `torch.randn`, which cannot be reproduced across
+devices), and training-only members (`compute_losses`, `q_sample`) are absent.
+"""
+from __future__ import annotations
+
+from typing import Mapping, Optional
+
+import torch
+
+from .engine import Engine
+from ._lib import CldError
+
+
+def cfg_get(cfg, path: str, default=None):
+    """Read 'a.b' from a dict- or attribute-style config (reference configs are both)."""
+    cur = cfg
+    for p in path.split("."):
+        if cur is None:
+            return default
+        if isinstance(cur, Mapping):
+            cur = cur.get(p, None)
+        else:
+            cur = getattr(cur, p, None)
+    return default if cur is None else cur
+
+
+def repeat_by_expand_at(x, repeats: int, dim: int = 0):
+    """tbsim.utils.tensor_utils.repeat_by_expand_at (tensor_utils.py:668-681) for tensors / dicts:
+    each entry is repeated `repeats` times consecutively along `dim`."""
+    if isinstance(x, Mapping):
+        return {k: repeat_by_expand_at(v, repeats, dim) for k, v in x.items()}
+    if isinstance(x, torch.Tensor):
+        return x if repeats == 1 else x.repeat_interleave(repeats, dim=dim)
+    return x
+
+
+class _UnetSurface:
+    """`dm.model(x, aux_info, t)` -- TemporalMapUnet.forward (temporal.py:122-180)."""
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+
+    def __call__(self, x, aux_info, time):
+        cond = aux_info["cond_feat"]
+        four_d = x.dim() == 4                      # [BN, M, T, D] with cond [BN, M, C]  (temporal.py:127-135)
+        if four_d:
+            BN, M, T, _ = x.shape
+            x = x.reshape(BN * M, T, -1)
+            cond = cond.reshape(BN * M, -1)
+            time = time.repeat_interleave(M, dim=0)
+        time = torch.as_tensor(time).reshape(-1).to("cpu")
+        if time.numel() == 1:
+            time = time.expand(x.shape[0])
+        vals = torch.unique(time)
+        if vals.numel() == 1:
+            eps = self.engine.unet_forward(x, cond, int(vals[0]))
+        else:                                      # per-row timesteps: one launch group per distinct value
+            eps = torch.empty(x.shape, dtype=torch.float32, device=self.engine.device)
+            for v in vals.tolist():
+                idx = (time == v).nonzero().reshape(-1).to(self.engine.device)
+                eps[idx] = self.engine.unet_forward(x.to(self.engine.device)[idx], cond.to(self.engine.device)[idx], int(v))
+        return eps.reshape(BN, M, T, -1) if four_d else eps
+
+
+class DmModel:
+    def __init__(self, algo_config=None, modality_shapes=None, n_timesteps: int = 100, device="cuda:0",
+                 engine: Optional[Engine] = None):
+        self.n_timesteps = int(n_timesteps)
+        self.stride = 1
+        self.horizon = cfg_get(algo_config, "horizon", 52)
+        self.dt = cfg_get(algo_config, "step_time", 0.1)
+        if self.horizon != 52 or cfg_get(algo_config, "vae.latent_size", 4) != 4 or \
+                cfg_get(algo_config, "cond_feat_dim", 256) != 256:
+            raise CldError("only the reference architecture (horizon 52, latent 4, cond 256) is built")
+        self.engine = engine or Engine(n_timesteps=n_timesteps, device=device,
+                                       dynamics=cfg_get(algo_config, "dynamics"),
+                                       norm_info=cfg_get(algo_config, "nusc_norm_info.diffuser"),
+                                       step_time=self.dt)
+        self.device = self.engine.device
+        self.model = _UnetSurface(self.engine)
+        for name in ("x_t_cof", "noise_cof", "posterior_log_variance_clipped"):
+            setattr(self, name, torch.from_numpy(getattr(self.engine, name)).to(self.device))
+
+    # nn.Module-compatible conveniences used by the callers
+    def load_state_dict(self, sd, strict=True):
+        self.engine.load_state_dict(sd, strict=strict)
+        self.engine.finalize()
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, data_batch, aux_info, algo_config, **kw):
+        return self.forward(data_batch, aux_info, algo_config, **kw)
+
+    # ---- dm_model.py:98-142 ------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data_batch, aux_info, algo_config, noise: Optional[Mapping] = None, seed: int = 0):
+        return self.sample_traj(data_batch, algo_config, aux_info, noise=noise, seed=seed)
+
+    def sample_traj(self, data_batch, algo_config, aux_info, noise: Optional[Mapping] = None, seed: int = 0):
+        batch_size = data_batch["history_positions"].size()[0]
+        num_samp = int(cfg_get(algo_config, "num_samp", 1))
+        BN = batch_size * num_samp
+        aux_info = repeat_by_expand_at(aux_info, repeats=num_samp, dim=0)
+        if noise is not None:
+            x_T, z = noise["x_T"], noise.get("noise")
+        else:   # same draw count as the reference (one for x_T, one per step), from torch's device generator
+            x_T = torch.randn(BN, 52, 4, device=self.device)
+            z = torch.randn(self.n_timesteps, BN, 52, 4, device=self.device)
+        x_T = torch.as_tensor(x_T).reshape(BN, 52, 4)
+        x0, x1, logp = self.engine.sample(x_T, aux_info["cond_feat"], noise=z, seed=seed)
+        return {"pred_traj": x0, "x1": x1, "log_prob_final": logp, "aux_info": aux_info}
+
+    # ---- dm_model.py:144-163 -----------------------------------------------------------
+    def _t_scalar(self, t) -> int:
+        t = torch.as_tensor(t).reshape(-1)
+        v = int(t[0])
+        if t.numel() > 1 and not bool((t == v).all()):
+            raise CldError("the sampler surface takes one timestep for the whole batch (dm_model.py:122)")
+        return v
+
+    def x_Tminus1(self, x, t, aux_info, noise=None):
+        i = self._t_scalar(t)
+        if noise is None:
+            noise = torch.randn(x.shape, device=self.device)
+        xn, mean, sigma = self.engine.ddpm_step(x, aux_info["cond_feat"], i, noise)
+        return xn, mean, torch.full((x.shape[0], 1, 1), sigma, device=self.device)
+
+    def x_tminus1_mean_var(self, xt, noise, t):
+        i = self._t_scalar(t)
+        mean = float(self.engine.x_t_cof[i]) * xt - float(self.engine.noise_cof[i]) * noise
+        logvar = torch.full((xt.shape[0], 1, 1), float(self.engine.posterior_log_variance_clipped[i]), device=xt.device)
+        return mean, logvar
+
+    # ---- dm_model.py:165-174 -----------------------------------------------------------
+    def log_prob(self, x_t, x_t_minus_1, aux_info, t):
+        return self.engine.log_prob(x_t, x_t_minus_1, aux_info["cond_feat"], self._t_scalar(t))

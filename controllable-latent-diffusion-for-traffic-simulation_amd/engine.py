@@ -1,0 +1,192 @@
+"""Engine: one libcld_hip handle + its device workspace, driven with torch CUDA tensors.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic of the path
+runs in the HIP library behind the C-ABI of include/cld.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CldConfig, CldError
+
+T, D, COND = 52, 4, 256
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Owns a `cld_handle`.  Weights come in under the reference's state_dict names."""
+
+    def __init__(self, n_timesteps: int = 100, device="cuda:0", dynamics: Optional[Mapping] = None,
+                 norm_info=None, step_time: float = 0.1):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise CldError("the CLD sampling path runs on an MI355X only (device must be cuda:N); no CPU fallback")
+        if not torch.cuda.is_available():
+            raise CldError("no HIP device visible; the CLD sampling path has no CPU fallback")
+        cfg = CldConfig()
+        self.lib.cld_default_config(C.byref(cfg))
+        cfg.n_timesteps = int(n_timesteps)
+        cfg.step_time = float(step_time)
+        if dynamics is not None:      # config.yaml:134-141
+            if "acce_bound" in dynamics:
+                cfg.acce_bound[0], cfg.acce_bound[1] = map(float, dynamics["acce_bound"])
+            if "max_steer" in dynamics:
+                cfg.max_steer = float(dynamics["max_steer"])
+            if "max_yawvel" in dynamics:
+                cfg.max_yawvel = float(dynamics["max_yawvel"])
+        if norm_info is not None:     # config.yaml:161-164: [mean(6), std(6)]
+            for i in range(6):
+                cfg.norm_mean[i] = float(norm_info[0][i])
+                cfg.norm_std[i] = float(norm_info[1][i])
+        self.cfg = cfg
+        self.n_timesteps = int(n_timesteps)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.cld_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise CldError(f"cld_create failed ({rc})")
+        self._ws = None
+        self._finalized = False
+        n = self.n_timesteps
+        xc, nc, lv = (np.empty(n, np.float32) for _ in range(3))
+        self._check(self.lib.cld_get_schedule(self._h, xc.ctypes.data, nc.ctypes.data, lv.ctypes.data), "cld_get_schedule")
+        self.x_t_cof, self.noise_cof, self.posterior_log_variance_clipped = xc, nc, lv
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc, what):
+        _lib.check(self._h, rc, what)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, B: int):
+        need = int(self.lib.cld_workspace_bytes(self._h, B))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel())
+
+    def _f32(self, t: torch.Tensor, shape=None) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise CldError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.cld_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Mapping, strict: bool = True):
+        """Accepts reference keys ('model.*', 'lstm_dec.*'; 'dm.' / 'vae.lstmvae.' prefixes stripped)."""
+        if self._finalized:
+            raise CldError("weights already finalized")
+        for k, v in sd.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            rc = self.lib.cld_load_weight(self._h, k.encode(), a.ctypes.data, a.size)
+            if rc != 0 and strict:
+                self._check(rc, f"cld_load_weight('{k}')")
+        return self
+
+    def finalize(self):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_finalize(self._h, self._stream()), "cld_finalize")
+        self._finalized = True
+        return self
+
+    # ------------------------------------------------------------------ compute
+    def unet_forward(self, x, cond, t_idx: int):
+        x = self._f32(x)
+        B = x.shape[0]
+        x = self._f32(x, (B, T, D)); cond = self._f32(cond, (B, COND))
+        eps = torch.empty_like(x)
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_unet_forward(self._h, _ptr(x), _ptr(cond), int(t_idx), _ptr(eps), B, ws, wsn,
+                                                  self._stream()), "cld_unet_forward")
+        return eps
+
+    def ddpm_step(self, x, cond, t_idx: int, z):
+        x = self._f32(x)
+        B = x.shape[0]
+        x = self._f32(x, (B, T, D)); cond = self._f32(cond, (B, COND))
+        z = None if z is None else self._f32(z, (B, T, D))
+        xn, mean = torch.empty_like(x), torch.empty_like(x)
+        sigma = C.c_float()
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_ddpm_step(self._h, _ptr(x), _ptr(cond), int(t_idx), _ptr(z), _ptr(xn), _ptr(mean),
+                                               C.byref(sigma), B, ws, wsn, self._stream()), "cld_ddpm_step")
+        return xn, mean, float(sigma.value)
+
+    def sample(self, x_T, cond, noise=None, seed: int = 0, want_x1=True, want_logp=True):
+        x_T = self._f32(x_T)
+        B = x_T.shape[0]
+        x_T = self._f32(x_T, (B, T, D)); cond = self._f32(cond, (B, COND))
+        n = self.n_timesteps
+        noise = None if noise is None else self._f32(noise, (n, B, T, D))
+        x0 = torch.empty_like(x_T)
+        x1 = torch.empty_like(x_T) if want_x1 else None
+        logp = torch.empty(B, dtype=torch.float32, device=self.device) if want_logp else None
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_sample(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), n, _ptr(x0), _ptr(x1),
+                                            _ptr(logp), B, C.c_uint64(seed), ws, wsn, self._stream()), "cld_sample")
+        return x0, x1, logp
+
+    def log_prob(self, x_t, x_tm1, cond, t_idx: int):
+        x_t = self._f32(x_t)
+        M = x_t.shape[0]
+        x_t = self._f32(x_t, (M, T, D)); x_tm1 = self._f32(x_tm1, (M, T, D)); cond = self._f32(cond, (M, COND))
+        out = torch.empty(M, dtype=torch.float32, device=self.device)
+        ws, wsn = self._workspace(M)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_log_prob(self._h, _ptr(x_t), _ptr(x_tm1), _ptr(cond), int(t_idx), _ptr(out), M,
+                                              ws, wsn, self._stream()), "cld_log_prob")
+        return out
+
+    def lstm_decode(self, z, cond):
+        z = self._f32(z)
+        B = z.shape[0]
+        z = self._f32(z, (B, T, D)); cond = self._f32(cond, (B, COND))
+        act = torch.empty(B, T, 2, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_lstm_decode(self._h, _ptr(z), _ptr(cond), _ptr(act), B, self._stream()),
+                        "cld_lstm_decode")
+        return act
+
+    def action_to_state(self, act, curr_states, scaled_input=True, descaled_output=False):
+        act = self._f32(act)
+        B = act.shape[0]
+        act = self._f32(act, (B, T, 2)); cs = self._f32(curr_states, (B, 4))
+        traj = torch.empty(B, T, 6, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_action_to_state(self._h, _ptr(act), _ptr(cs), _ptr(traj), B, int(scaled_input),
+                                                     int(descaled_output), self._stream()), "cld_action_to_state")
+        return traj
+
+    def decode(self, z, cond, curr_states, descaled_output=True, want_act=False):
+        z = self._f32(z)
+        B = z.shape[0]
+        z = self._f32(z, (B, T, D)); cond = self._f32(cond, (B, COND)); cs = self._f32(curr_states, (B, 4))
+        traj = torch.empty(B, T, 6, dtype=torch.float32, device=self.device)
+        act = torch.empty(B, T, 2, dtype=torch.float32, device=self.device) if want_act else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_decode(self._h, _ptr(z), _ptr(cond), _ptr(cs), _ptr(traj), _ptr(act), B,
+                                            int(descaled_output), self._stream()), "cld_decode")
+        return (traj, act) if want_act else traj

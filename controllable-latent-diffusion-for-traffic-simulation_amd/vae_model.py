@@ -1,0 +1,56 @@
+"""Host-side mirror of the VAE-decoder half of the reference call surface:
+`LSTMVAE.lstm_dec(z, context)` (models/vae/lstm_vae.py:44-52) and
+`VaeModel.convert_action_to_state_and_action / scale_traj / descale_traj`
+(models/vae/vae_model.py:100-173), as used at
+src/trainers/guide_dm_trainer.py:97-98,195-196,210-211.
+The encoder (`traj2z`) and `ContextEncoder` are "next" rows and not built.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .dm_model import cfg_get
+from .engine import Engine
+
+
+class LSTMVAE:
+    def __init__(self, engine: Engine):
+        self.engine = engine
+
+    def lstm_dec(self, z, context):
+        return self.engine.lstm_decode(z, context)
+
+
+class VaeModel:
+    def __init__(self, algo_config=None, train_config=None, modality_shapes=None, device="cuda:0",
+                 engine: Optional[Engine] = None):
+        self.engine = engine or Engine(device=device, dynamics=cfg_get(algo_config, "dynamics"),
+                                       norm_info=cfg_get(algo_config, "nusc_norm_info.diffuser"))
+        self.lstmvae = LSTMVAE(self.engine)
+        self.default_chosen_inds = [0, 1, 2, 3, 4, 5]
+        self.dt = 0.1
+        c = self.engine.cfg
+        self.add_coeffs = torch.tensor(list(c.norm_mean), dtype=torch.float32)
+        self.div_coeffs = torch.tensor(list(c.norm_std), dtype=torch.float32)
+
+    def load_state_dict(self, sd, strict=True):
+        self.engine.load_state_dict(sd, strict=strict)
+        return self
+
+    def convert_action_to_state_and_action(self, x_out, curr_states, scaled_input=True, descaled_output=False):
+        four_d = x_out.dim() == 4          # vae_model.py:108-111
+        if four_d:
+            B, N, T, _ = x_out.shape
+            x_out = x_out.reshape(B * N, T, -1)
+        out = self.engine.action_to_state(x_out, curr_states, scaled_input, descaled_output)
+        return out.reshape(B, N, T, -1) if four_d else out
+
+    def scale_traj(self, traj, chosen_inds=()):
+        inds = list(chosen_inds) or self.default_chosen_inds      # (x - mean) / std, vae_model.py:152
+        return (traj - self.add_coeffs[inds].to(traj.device)) / self.div_coeffs[inds].to(traj.device)
+
+    def descale_traj(self, traj, chosen_inds=()):
+        inds = list(chosen_inds) or self.default_chosen_inds      # x * std + mean, vae_model.py:170
+        return traj * self.div_coeffs[inds].to(traj.device) + self.add_coeffs[inds].to(traj.device)

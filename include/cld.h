@@ -1,0 +1,149 @@
+/*
+ * cld.h -- C-ABI of the MI355X-native CLD latent-diffusion sampling path.
+ *
+ * The reference (RoboSafe-Lab/Controllable-Latent-Diffusion-for-Traffic-Simulation)
+ * has no FFI layer: its seam is Python method calls on nn.Modules.  Each entry
+ * point below replaces one of those calls (reference file:line given per
+ * function); the Python host mirror in
+ * `controllable-latent-diffusion-for-traffic-simulation_amd/` binds them with
+ * ctypes and keeps the reference's method names and dict keys.
+ *
+ * Conventions
+ *   - plain C types only; no torch / C++ types cross this boundary.
+ *   - every `const float*` / `float*` that is not marked HOST is a DEVICE pointer
+ *     to contiguous fp32; the caller owns all buffers (inputs and outputs).
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it and the
+ *     call returns without synchronising.  Calls on one stream are ordered.
+ *   - no allocation inside the compute calls: scratch comes from the caller
+ *     (`cld_workspace_bytes`), so calls are capturable into a hipGraph.
+ *   - return value: 0 = OK, negative = error (never throws);
+ *     `cld_last_error` gives the message of the last failure on that handle.
+ *   - one handle per device; distinct handles are independent.
+ *
+ * Fixed architecture (reference config.yaml:91-172; validated by cld_create):
+ *   horizon T = 52, latent D = 4, cond C = 256, U-Net dims 4 -> 64 -> 128 -> 256
+ *   (TemporalMapUnet, src/tbsim/models/temporal.py:49-180), LSTM decoder hidden 64.
+ */
+#ifndef CLD_H
+#define CLD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cld_handle_s* cld_handle;
+
+enum {
+    CLD_OK = 0,
+    CLD_ERR_ARG = -1,       /* bad argument / unsupported configuration      */
+    CLD_ERR_STATE = -2,     /* weights missing / not finalized               */
+    CLD_ERR_WORKSPACE = -3, /* workspace too small                            */
+    CLD_ERR_HIP = -4        /* a HIP runtime call failed                      */
+};
+
+typedef struct cld_config {
+    int32_t horizon;        /* 52   config.yaml:107                                   */
+    int32_t latent_dim;     /* 4    config.yaml:133 vae.latent_size                   */
+    int32_t cond_dim;       /* 256  config.yaml:118 cond_feat_dim                     */
+    int32_t base_dim;       /* 32   config.yaml:106                                   */
+    int32_t dim_mults[3];   /* 2,4,8 config.yaml:109-112                              */
+    int32_t hidden;         /* 64   config.yaml:132 vae.hidden_size                   */
+    int32_t n_timesteps;    /* 100  models/dm/dm_model.py:20 (ctor default)           */
+    float step_time;        /* 0.1  models/vae/vae_model.py:43 (self.dt)              */
+    float acce_bound[2];    /* -10, 8        config.yaml:138-140                      */
+    float v_bound[2];       /* -10, 30       src/tbsim/dynamics/unicycle.py:10        */
+    float max_steer;        /* 0.5           config.yaml:136                          */
+    float max_yawvel;       /* 2*pi          config.yaml:137                          */
+    float norm_mean[6];     /* config.yaml:162  (x - mean) / std convention,          */
+    float norm_std[6];      /* config.yaml:163   models/vae/vae_model.py:152,170      */
+} cld_config;
+
+/* Fill `cfg` with the reference defaults listed above. */
+void cld_default_config(cld_config* cfg);
+
+/* Replaces DmModel.__init__ / LSTMVAE.__init__ (models/dm/dm_model.py:15-68,
+ * models/vae/lstm_vae.py:55-84): builds the cosine schedule buffers
+ * (dm_model.py:29-56) for cfg->n_timesteps on the current HIP device. */
+int cld_create(const cld_config* cfg, cld_handle* out);
+int cld_destroy(cld_handle h);
+const char* cld_last_error(cld_handle h);
+
+/* Replaces nn.Module.load_state_dict (src/trainers/dm_trainer.py:24-35,
+ * utils/trainer_utils.py:59-72).  `name` is the reference state_dict key:
+ * "model.*" for the U-Net (a leading "dm." is accepted and stripped),
+ * "lstm_dec.*" for the VAE decoder (leading "vae.lstmvae." / "lstmvae." accepted).
+ * `data` is a HOST pointer to `numel` fp32 values in the reference's layout
+ * (Conv1d [C_out,C_in,k], ConvTranspose1d [C_in,C_out,k], Linear [out,in], ...).
+ * Schedule buffer keys ("betas", ...) are accepted and ignored (rebuilt by cld_create).
+ * Unknown keys or wrong sizes return CLD_ERR_ARG. */
+int cld_load_weight(cld_handle h, const char* name, const float* data /*HOST*/, size_t numel);
+
+/* Re-lays the loaded weights out for the kernels (MFMA fragment order), folds the
+ * per-step time-embedding bias table, uploads everything.  Needs every "model.*"
+ * tensor; the decoder tensors are optional (cld_decode then returns CLD_ERR_STATE). */
+int cld_finalize(cld_handle h, void* stream);
+
+/* Scratch bytes the compute calls need for up to B agents. */
+size_t cld_workspace_bytes(cld_handle h, int32_t B);
+
+/* Schedule read-back (HOST out, n_timesteps floats each; any pointer may be NULL):
+ * x_t_cof, noise_cof, posterior_log_variance_clipped (dm_model.py:48-56). */
+int cld_get_schedule(cld_handle h, float* x_t_cof, float* noise_cof, float* post_log_var);
+
+/* eps = TemporalMapUnet.forward(x, {'cond_feat': cond}, t)
+ * (src/tbsim/models/temporal.py:122-180; called from dm_model.py:87,147,166).
+ * x [B,52,4], cond [B,256], t_idx: one timestep for all B rows (as in the sampler,
+ * dm_model.py:122), eps [B,52,4]. */
+int cld_unet_forward(cld_handle h, const float* x, const float* cond, int32_t t_idx, float* eps,
+                     int32_t B, void* workspace, size_t workspace_bytes, void* stream);
+
+/* (x_{t-1}, mean, sigma) = DmModel.x_Tminus1(x, t, aux_info)  (dm_model.py:144-163).
+ * z [B,52,4] is the caller's N(0,1) draw (the reference's randn_like, :153).
+ * x_next / mean [B,52,4] (either may be NULL); *sigma_host receives exp(0.5*logvar[t]). */
+int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx, const float* z,
+                  float* x_next, float* mean, float* sigma_host /*HOST*/, int32_t B,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* out = DmModel.forward(...)/sample_traj  (dm_model.py:98-142): the full ancestral
+ * loop i = steps-1 .. 0 (steps must equal n_timesteps; the reference has stride 1).
+ * x_T [B,52,4]; noise [steps,B,52,4], slab s feeds loop iteration s (i = steps-1-s),
+ * the reference RNG order (one randn_like per step incl. the masked t=0 one); if
+ * noise == NULL a counter-based on-device generator seeded with `seed` is used
+ * (throughput runs; not parity-comparable with torch's RNG).
+ * Outputs (any may be NULL): x0 = 'pred_traj' [B,52,4], x1 = 'x1' [B,52,4],
+ * logp = 'log_prob_final' [B]. */
+int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* cond, int32_t steps,
+               float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* out = DmModel.log_prob(x_t, x_{t-1}, aux_info, t)  (dm_model.py:165-174):
+ * mean over (T, D) of log N(x_{t-1}; mean(x_t, eps), sigma_t).  Forward only. */
+int cld_log_prob(cld_handle h, const float* x_t, const float* x_tm1, const float* cond, int32_t t_idx,
+                 float* out /*[M]*/, int32_t M, void* workspace, size_t workspace_bytes, void* stream);
+
+/* act = LSTMVAE.lstm_dec(z, cond)  (models/vae/lstm_vae.py:44-52), z [B,52,4],
+ * cond [B,256] -> act [B,52,2] (scaled acceleration, yaw-rate). */
+int cld_lstm_decode(cld_handle h, const float* z, const float* cond, float* act, int32_t B, void* stream);
+
+/* traj = VaeModel.convert_action_to_state_and_action(act, curr_states,
+ *        scaled_input, descaled_output)  (models/vae/vae_model.py:100-129) with
+ * unicyle_forward_dynamics(mode='parallel') (src/tbsim/models/diffuser_helpers.py:541-639).
+ * act [B,52,2], curr_states [B,4] = (x, y, v, yaw) -> traj [B,52,6]. */
+int cld_action_to_state(cld_handle h, const float* act, const float* curr_states, float* traj,
+                        int32_t B, int32_t scaled_input, int32_t descaled_output, void* stream);
+
+/* Both of the above in one launch (guide_dm_trainer.py:97-98): z -> traj [B,52,6];
+ * act_out [B,52,2] optional (NULL to skip). */
+int cld_decode(cld_handle h, const float* z, const float* cond, const float* curr_states,
+               float* traj, float* act_out, int32_t B, int32_t descaled_output, void* stream);
+
+/* Library build id (for the "native code loaded" check). */
+const char* cld_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLD_H */
