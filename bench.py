@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the CLD latent-diffusion sampling path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic agents: the full ancestral
+sampling loop (100 U-Net evaluations + DDPM updates, reference models/dm/dm_model.py:103-142)
+followed by LSTM decode + unicycle roll-out (guide_dm_trainer.py:97-98) and, for N > 1, the
+RCCL all-gather of the decoded trajectories at the rollout-step boundary.
+
+Workload at N = 1: BASELINE.json configs[1] -- 32 scenes x 32 agents (B = 1,024), 100 denoising
+steps, d = 256, seq 52, CFG off.  N > 1: weak scaling, every rank samples its own 32 x 32 shard
+(scenes are independent: no collective inside the loop).
+
+Prints ONE JSON line (rank 0): metric = denoising-step.agent/s over the whole job, plus
+`roofline` (dominant kernel vs. the fp32-MFMA peak, timed with HIP events inside the library)
+and `cpu_baseline` (the oracle on the host cores, bounded sample; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_STEP_AGENT = 119_232_512          # U-Net forward, SURVEY 8(d) / BASELINE.md section 2
+PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenes", type=int, default=32, help="scenes per GPU")
+    ap.add_argument("--agents", type=int, default=32, help="agents per scene")
+    ap.add_argument("--denoise-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from cld_amd import synth
+    from cld_amd.engine import Engine
+    from cld_amd.parallel import gather_trajectories
+
+    n = args.denoise_steps
+    B = args.scenes * args.agents
+    eng = Engine(n_timesteps=n, device=dev)
+    eng.load_state_dict(synth.make_unet_weights(0))            # PyTorch-default-like random init (no checkpoint ships)
+    eng.load_state_dict(synth.make_decoder_weights(0))
+    eng.finalize()
+
+    # synthetic inputs, resident in HBM before the timed region starts
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    cond = torch.randn(B, 256, device=dev, generator=g)
+    x_T = torch.randn(B, 52, 4, device=dev, generator=g)
+    noise = torch.randn(n, B, 52, 4, device=dev, generator=g)
+    cs = torch.zeros(B, 4, device=dev)
+    cs[:, 2] = torch.rand(B, device=dev, generator=g) * 15.0
+    gathered = torch.empty(world * B, 52, 6, device=dev) if distributed else None
+
+    def one_step():
+        x0, x1, logp = eng.sample(x_T, cond, noise=noise)
+        traj = eng.decode(x0, cond, cs, descaled_output=True)
+        if distributed:
+            gather_trajectories(traj, gathered)
+        return traj
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    if not args.no_profile:
+        eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        traj = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(traj).all()), "non-finite trajectories"
+
+    roof = None
+    if not args.no_profile:
+        ms, launches, flop = eng.profile_read()
+        eng.profile_enable(False)
+        if launches > 0 and ms > 0:
+            ach = flop / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_block_kernel<13,13,1,5,32,4,GN_MISH,32,1> (Conv1d 256->256 k5 + GroupNorm + Mish, L=13)",
+                    "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
+                    "flop_per_launch": flop / launches}
+
+    total_units = world * B * n * args.steps
+    value = total_units / dt
+    out = {
+        "metric": "denoising-step·agent/s", "value": round(value, 1), "unit": "step·agent/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 32 scenes x 32 agents per GPU, 100 denoising steps "
+                               "(DDPM ancestral loop of the reference), latent seq 52 x 4, cond 256, CFG off; "
+                               "+ LSTM decode + unicycle roll-out" + ("; RCCL all-gather of trajectories" if distributed else ""),
+                   "scenes_per_gpu": args.scenes, "agents_per_scene": args.agents, "agents_per_gpu": B,
+                   "denoise_steps": n, "weights": "random init (synth seed 0)"},
+        "scenes_per_s": round(world * args.scenes * args.steps / dt, 2),
+        "unet_tflops_effective": round(value * FLOP_PER_STEP_AGENT / 1e12, 2),
+        "roofline_whole_path_frac": round(value * FLOP_PER_STEP_AGENT / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+    }
+    if roof:
+        out["roofline"] = roof
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(B)
+    if rank == 0:
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(B):
+    """The oracle (CPU restatement, validated against the reference) on the host cores: a bounded
+    sample of the same workload -- the first CPU_STEPS denoising steps of the B-agent batch."""
+    import torch
+    from cld_amd import synth
+    from oracle import cld_oracle as O
+    CPU_STEPS = 6
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    w = O.to_torch(synth.make_unet_weights(0))
+    s = O.schedule(100)
+    cond = torch.randn(B, 256)
+    x = torch.randn(B, 52, 4)
+    z = torch.randn(B, 52, 4)
+    with torch.no_grad():
+        O.ddpm_step(w, s, x[:64], cond[:64], 99, z[:64])     # warm-up
+        t0 = time.perf_counter()
+        for k in range(CPU_STEPS):
+            x, _, _ = O.ddpm_step(w, s, x, cond, 99 - k, z)
+        dt = time.perf_counter() - t0
+    return {"value": round(B * CPU_STEPS / dt, 1), "unit": "step·agent/s", "cores": cores, "kind": "port",
+            "sample": f"{CPU_STEPS} denoising steps (t=99..{100 - CPU_STEPS}) of the same {B}-agent batch, torch "
+                      f"{torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

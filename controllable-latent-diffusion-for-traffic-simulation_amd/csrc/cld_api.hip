@@ -56,6 +56,11 @@ struct cld_handle_s {
     float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr;
     DecoderWeights dec{};
     DynParams dyn{};
+    // optional HIP-event timing of the dominant conv kernel (256->256 channels, L = 13), see cld_profile_*
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;     // pairs (start, stop)
+    size_t prof_used = 0;
+    double prof_flop = 0.0;              // algorithmic FLOP of the timed launches
 };
 
 namespace {
@@ -179,14 +184,31 @@ Ws carve(void* ws, int b_pad) {
 }
 inline int pad16(int b) { return (b + 15) / 16 * 16; }
 
-hipError_t run_conv(const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
+hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
                     const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
     ConvArgs a{};
     a.x1 = x1; a.x2 = x2; a.c1_real = l.c1_real; a.c1_pad = l.c1_pad; a.c2 = l.c2;
     a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
     if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
     a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
-    return launch_conv(l.g, a, b_pad, 0, s);
+    const bool timed = h->prof_on && l.g.l_in == 13 && l.g.ntaps == 5 && l.c_out == 256 && l.c1_real == 256;
+    if (!timed) return launch_conv(l.g, a, b_pad, 0, s);
+    if (h->prof_used + 2 > h->prof_ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t ev;
+            hipError_t e = hipEventCreate(&ev);
+            if (e != hipSuccess) return e;
+            h->prof_ev.push_back(ev);
+        }
+    }
+    hipError_t e = hipEventRecord(h->prof_ev[h->prof_used], s);
+    if (e != hipSuccess) return e;
+    e = launch_conv(l.g, a, b_pad, 0, s);
+    if (e != hipSuccess) return e;
+    e = hipEventRecord(h->prof_ev[h->prof_used + 1], s);
+    h->prof_used += 2;
+    h->prof_flop += 2.0 * (double)b_pad * l.g.lm * (double)(l.g.ntaps * (l.c1_pad + l.c2)) * l.c_out;
+    return e;
 }
 
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
@@ -195,7 +217,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     const float* tbr = h->tb + (size_t)t_idx * NCB;
     float* const* b = w.buf;
     hipError_t e;
-#define RC(...) do { e = run_conv(__VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
+#define RC(...) do { e = run_conv(h, __VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
     auto resblock = [&](const ResBlock& rb, const float* in1, const float* in2, float* out) -> hipError_t {
         const float* r = in1;           // identity residual reads the block input
         if (rb.has_res) { RC(rb.res, in1, in2, b[0], nullptr); r = b[0]; }
@@ -274,8 +296,32 @@ int cld_create(const cld_config* cfg, cld_handle* out) {
     return CLD_OK;
 }
 
+int cld_profile_enable(cld_handle h, int32_t on) {
+    if (!h) return CLD_ERR_ARG;
+    h->prof_on = on != 0;
+    h->prof_used = 0;
+    h->prof_flop = 0.0;
+    return CLD_OK;
+}
+
+int cld_profile_read(cld_handle h, double* total_ms, int64_t* launches, double* total_flop) {
+    if (!h) return CLD_ERR_ARG;
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        HIPCK(h, hipEventSynchronize(h->prof_ev[i + 1]));
+        float t = 0.f;
+        HIPCK(h, hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)(h->prof_used / 2);
+    if (total_flop) *total_flop = h->prof_flop;
+    return CLD_OK;
+}
+
 int cld_destroy(cld_handle h) {
     if (!h) return CLD_ERR_ARG;
+    for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
     for (void* p : h->dev_allocs) (void)hipFree(p);
     delete h;
     return CLD_OK;

@@ -190,3 +190,13 @@ class Engine:
             self._check(self.lib.cld_decode(self._h, _ptr(z), _ptr(cond), _ptr(cs), _ptr(traj), _ptr(act), B,
                                             int(descaled_output), self._stream()), "cld_decode")
         return (traj, act) if want_act else traj
+
+    # ------------------------------------------------------------------ measurement
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.cld_profile_enable(self._h, int(on)), "cld_profile_enable")
+
+    def profile_read(self):
+        """-> (summed ms, launches, algorithmic FLOP) of the dominant conv kernel since profile_enable(True)."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        self._check(self.lib.cld_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl)), "cld_profile_read")
+        return ms.value, n.value, fl.value

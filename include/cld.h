@@ -140,6 +140,14 @@ int cld_action_to_state(cld_handle h, const float* act, const float* curr_states
 int cld_decode(cld_handle h, const float* z, const float* cond, const float* curr_states,
                float* traj, float* act_out, int32_t B, int32_t descaled_output, void* stream);
 
+/* Measurement aid for bench.py (no reference counterpart): while enabled, every launch of the
+ * dominant kernel -- the Conv1d(256->256, k=5) + GroupNorm + Mish block at L = 13, 7 launches
+ * per U-Net evaluation, temporal.py:16-45 -- is bracketed by HIP events on the caller's stream.
+ * cld_profile_read waits for the recorded events and returns the summed kernel time, the
+ * number of launches and their algorithmic FLOP (2 * rows * K * N); enable(…, 1) resets. */
+int cld_profile_enable(cld_handle h, int32_t on);
+int cld_profile_read(cld_handle h, double* total_ms /*HOST*/, int64_t* launches /*HOST*/, double* total_flop /*HOST*/);
+
 /* Library build id (for the "native code loaded" check). */
 const char* cld_version(void);
 
