@@ -115,7 +115,7 @@ def main():
             ach = flop / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_block_kernel<13,13,1,5,32,4,GN_MISH,32,1> (Conv1d 256->256 k5 + GroupNorm + Mish, L=13)",
+                    "kernel": "conv_block_kernel<13,13,1,5,32,4,1,32,1> (Conv1d k5 -> 256 ch + GroupNorm + Mish at L=13; 7 launches/step with 256 input channels, 1 with 128)",
                     "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
                     "flop_per_launch": flop / launches}
 
@@ -147,18 +147,31 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (a GPU box
+    hands each 1-GPU job a share of its cores; oversubscribing the share makes torch crawl)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("CLD_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(B):
     """The oracle (CPU restatement, validated against the reference) on the host cores: a bounded
     sample of the same workload -- the first CPU_STEPS denoising steps of the B-agent batch."""
     import torch
     from cld_amd import synth
     from oracle import cld_oracle as O
-    CPU_STEPS = 6
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     w = O.to_torch(synth.make_unet_weights(0))
     s = O.schedule(100)
@@ -168,11 +181,15 @@ def cpu_baseline(B):
     with torch.no_grad():
         O.ddpm_step(w, s, x[:64], cond[:64], 99, z[:64])     # warm-up
         t0 = time.perf_counter()
+        O.ddpm_step(w, s, x, cond, 99, z)                    # probe: sizes the bounded sample (~12 s of CPU work)
+        probe = time.perf_counter() - t0
+        CPU_STEPS = max(1, min(8, int(12.0 / max(probe, 1e-3))))
+        t0 = time.perf_counter()
         for k in range(CPU_STEPS):
-            x, _, _ = O.ddpm_step(w, s, x, cond, 99 - k, z)
+            x, _, _ = O.ddpm_step(w, s, x, cond, 98 - k, z)
         dt = time.perf_counter() - t0
     return {"value": round(B * CPU_STEPS / dt, 1), "unit": "step·agent/s", "cores": cores, "kind": "port",
-            "sample": f"{CPU_STEPS} denoising steps (t=99..{100 - CPU_STEPS}) of the same {B}-agent batch, torch "
+            "sample": f"{CPU_STEPS} denoising steps (t=98..{99 - CPU_STEPS}) of the same {B}-agent batch, torch "
                       f"{torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}
 
 

@@ -60,6 +60,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CldError(f"{LIB_PATH} not found: build the HIP library first "
                        f"(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 (same SONAME as
+    # /opt/rocm's).  Importing torch first makes libcld_hip.so bind to that already-loaded copy, so
+    # torch's streams / device pointers and our launches live in the same runtime.  Loading this
+    # library first would pull /opt/rocm's runtime in beside torch's and break device init.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it

@@ -35,9 +35,10 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)) == x * n / (n + 2), n = e^x (e^x + 2): one exp, no cancellation.
-    const float e = expf(fminf(x, 30.0f));
+    // v_exp_f32 / v_rcp_f32 are 1-ulp instructions: relative error ~2e-7, far inside the parity bar.
+    const float e = __expf(fminf(x, 30.0f));
     const float n = e * (e + 2.0f);
-    return x * (n / (n + 2.0f));
+    return x * n * __frcp_rn(n + 2.0f);
 }
 
 template <int W> struct VecT;
@@ -51,7 +52,8 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
     constexpr int LP = L_IN + 2;           // LDS rows per agent (2 halo rows shared with the neighbour)
     constexpr int AROWS = AG * LP + 2;
     constexpr int KCP = KC + 4;            // padded LDS row, floats (keeps 16-B alignment)
-    constexpr int ABUF = AROWS * KCP;      // floats per A buffer
+    constexpr int ABUF = AROWS * KCP;      // floats per A image
+    constexpr int ABUFP = ABUF + KCP;      // + one dump row for the staging pieces past the tile
     constexpr int NT = 16 * NWN;
     constexpr int OP = NT + 4;             // padded row of the output tile
     constexpr int NKG = KC / 16;           // 16-channel groups per chunk
@@ -78,45 +80,41 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
     const int nchunk = (p.c1_pad + p.c2) / KC;
 
     // ---- staging map: piece i of this thread -> (global row, LDS offset) ------------------
+    // Every piece loads and stores unconditionally (no divergent branches, so the compiler can count
+    // its vmcnt waits): pieces past the tile read this thread's piece 0 again and land in a dump row
+    // behind the image.
     const int pc4 = (tid % PPR) * 4;
     int soff[NPIECE];
     int grow[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
         const int idx = tid + 256 * i;
-        const int r = idx / PPR;
+        const bool ok = idx < NPC;
+        const int r = ok ? idx / PPR : tid / PPR;
         const int a = r / L_IN;
         const int l = r - a * L_IN;
-        soff[i] = (idx < NPC) ? (2 + a * LP + l) * KCP + pc4 : -1;
+        soff[i] = ok ? (2 + a * LP + l) * KCP + pc4 : AROWS * KCP + pc4;
         grow[i] = b0 * L_IN + r;
     }
     v4f st[NPIECE];
     auto load_chunk = [&](int c) {
-        const int cb = c * KC + pc4;
-        if (c * KC < p.c1_pad) {
-            const bool real = cb < p.c1_real;
+        const int cv = c * KC;                          // virtual input channel of this chunk
+        const bool first = cv < p.c1_pad;               // wave-uniform: which source feeds the chunk
+        const float* src = first ? p.x1 : p.x2;
+        const int stride = first ? p.c1_real : p.c2;
+        int cb = (first ? cv : cv - p.c1_pad) + pc4;
+        const bool real = !first || cb < p.c1_real;     // only the 4-channel latent has a padded chunk
+        cb = real ? cb : 0;
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) {
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (soff[i] >= 0 && real)
-                    v = *reinterpret_cast<const v4f*>(p.x1 + (size_t)grow[i] * p.c1_real + cb);
-                st[i] = v;
-            }
-        } else {
-            const int cb2 = cb - p.c1_pad;
-#pragma unroll
-            for (int i = 0; i < NPIECE; ++i) {
-                v4f v = {0.f, 0.f, 0.f, 0.f};
-                if (soff[i] >= 0) v = *reinterpret_cast<const v4f*>(p.x2 + (size_t)grow[i] * p.c2 + cb2);
-                st[i] = v;
-            }
+        for (int i = 0; i < NPIECE; ++i) {
+            const v4f v = *reinterpret_cast<const v4f*>(src + (size_t)grow[i] * stride + cb);
+            st[i] = real ? v : v4f{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_chunk = [&](int buf) {
-        float* A = lds + buf * ABUF;
+        float* A = lds + buf * ABUFP;
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i)
-            if (soff[i] >= 0) *reinterpret_cast<v4f*>(A + soff[i]) = st[i];
+        for (int i = 0; i < NPIECE; ++i) *reinterpret_cast<v4f*>(A + soff[i]) = st[i];
     };
 
     // ---- A fragment offsets: lane (i = lane&15, kk = lane>>4) of M-tile m --------------------
@@ -142,23 +140,31 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
 
     // ---- prologue: zero both images (halo rows stay zero for the whole kernel), stage chunk 0 ----
     load_chunk(0);
-    v4f bnext = *wptr(0, 0);
-    for (int i = tid * 4; i < 2 * ABUF; i += 1024) *reinterpret_cast<v4f*>(lds + i) = v4f{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them
+    auto wptr_lin = [&](int c, int it) { return wptr(c + it / NIT, it % NIT); };   // `it` may run past the chunk
+    v4f bq0 = *wptr(0, 0);
+    v4f bq1 = (1 / NIT < nchunk) ? *wptr_lin(0, 1) : bq0;
+    // zero the halo rows of both images: rows 0,1 and the 2 rows behind every agent
+    for (int i = tid; i < 2 * (AG + 1) * 2 * (KCP / 4); i += 256) {
+        const int q = i % (KCP / 4), hr = (i / (KCP / 4)) % (2 * (AG + 1)), buf = i / ((KCP / 4) * 2 * (AG + 1));
+        const int g = hr >> 1;                          // gap index: 0 = leading rows, g>0 = behind agent g-1
+        const int row = (g == 0 ? 0 : g * LP) + (hr & 1);
+        *reinterpret_cast<v4f*>(lds + buf * ABUFP + row * KCP + q * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
     store_chunk(0);
     __syncthreads();
 
     for (int c = 0; c < nchunk; ++c) {
-        const float* A = lds + (c & 1) * ABUF;
+        const float* A = lds + (c & 1) * ABUFP;
         const bool more = (c + 1 < nchunk);
         v4f af[2][NMT];
 #pragma unroll
         for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(A + aoff[m]);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const v4f bcur = bnext;
-            if (it + 1 < NIT) bnext = *wptr(c, it + 1);
-            else if (more) bnext = *wptr(c + 1, 0);
+            const v4f bcur = bq0;
+            bq0 = bq1;
+            if (c + (it + 2) / NIT < nchunk) bq1 = *wptr_lin(c, it + 2);
             if (it == 0 && more) load_chunk(c + 1);      // next chunk's activations: in flight under this chunk's MFMAs
             if (it + 1 < NIT) {
                 const int t1 = (it + 1) / KGW, g1 = (it + 1) % KGW;
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int EPI, int GS, int OSTR>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = MT / LM;
-    constexpr int ABUF = (AG * (L_IN + 2) + 2) * (KC + 4);
+    constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 4);   // image + dump row
     constexpr int OTILE = MT * (16 * NWN + 4);     // the epilogue's output tile aliases the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, EPI, GS, OSTR>;

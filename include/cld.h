@@ -141,8 +141,9 @@ int cld_decode(cld_handle h, const float* z, const float* cond, const float* cur
                float* traj, float* act_out, int32_t B, int32_t descaled_output, void* stream);
 
 /* Measurement aid for bench.py (no reference counterpart): while enabled, every launch of the
- * dominant kernel -- the Conv1d(256->256, k=5) + GroupNorm + Mish block at L = 13, 7 launches
- * per U-Net evaluation, temporal.py:16-45 -- is bracketed by HIP events on the caller's stream.
+ * dominant kernel instance -- the Conv1d(k=5) + GroupNorm + Mish block producing 256 channels at
+ * L = 13 (conv_block_kernel<13,13,1,5,32,4,1,32,1>: 7 launches with 256 input channels and one with
+ * 128 per U-Net evaluation, temporal.py:16-45) -- is bracketed by HIP events on the caller's stream.
  * cld_profile_read waits for the recorded events and returns the summed kernel time, the
  * number of launches and their algorithmic FLOP (2 * rows * K * N); enable(…, 1) resets. */
 int cld_profile_enable(cld_handle h, int32_t on);
