@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libcld_hip.so")
+# CLD_LIB_PATH selects an experimental build of the same library (never a different backend)
+LIB_PATH = os.environ.get("CLD_LIB_PATH") or os.path.join(PKG_DIR, "libcld_hip.so")
 
 
 class CldError(RuntimeError):
@@ -46,6 +47,7 @@ SIGNATURES = {
     "cld_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "cld_profile_enable": (C.c_int, [_P, C.c_int32]),
     "cld_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "cld_debug_stamps": (C.c_int, [_P, _P, C.c_int32]),
     "cld_version": (C.c_char_p, []),
 }
 

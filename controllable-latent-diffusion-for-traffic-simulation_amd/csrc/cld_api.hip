@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -31,7 +32,8 @@ const BlockDef kBlocks[12] = {
 };
 
 struct ConvLayer {
-    ConvGeom g{};
+    ConvGeom g{};        // kc / nwn / ks are filled per launch by pick_tiling()
+    bool has_a = false, has_b = false;   // which tilings have a kernel instance
     float *wfrag = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;
     int c_out = 0, c1_real = 0, c1_pad = 0, c2 = 0, ly = 0, off0 = 0, orow0 = 0;
     int cb_off = -1;    // offset into the 1792-wide cond/time bias rows, -1 = none
@@ -61,6 +63,9 @@ struct cld_handle_s {
     std::vector<hipEvent_t> prof_ev;     // pairs (start, stop)
     size_t prof_used = 0;
     double prof_flop = 0.0;              // algorithmic FLOP of the timed launches
+    // diagnostic (-DCLD_STAMPS builds): launch index within a U-Net evaluation that receives the stamp buffer
+    unsigned long long* stamp_buf = nullptr;
+    int stamp_layer = -1, launch_counter = 0;
 };
 
 namespace {
@@ -151,21 +156,38 @@ void build_schedule(cld_handle h) {
 
 double mish_d(double x) { return x * std::tanh(std::log1p(std::exp(x))); }
 
-// MFMA-fragment weight packing.  Slab (chunk c, tap t, group kg) holds, for every 16-column N tile nt
-// and lane, the 4 values W[co = 16 nt + (lane & 15)][ci = c*KC + 16 kg + 4 (lane >> 4) + s][tap t].
+// MFMA-fragment weight packing.  Slab (16-channel group kgg, tap t) holds, for every 16-column N tile nt
+// and lane, the 4 values W[co = 16 nt + (lane & 15)][ci = 16 kgg + 4 (lane >> 4) + s][tap t]; the layout
+// does not depend on the K-chunk size, so every tiling of a layer reads the same buffer.
 template <class F>
-std::vector<float> pack_conv_weights(F&& wget, int c_out, int cin_virtual, int ntaps, int kc) {
-    const int nchunk = cin_virtual / kc, nkg = kc / 16, ntn = c_out / 16;
-    std::vector<float> out((size_t)nchunk * ntaps * nkg * ntn * 256);
+std::vector<float> pack_conv_weights(F&& wget, int c_out, int cin_virtual, int ntaps) {
+    const int ngrp = cin_virtual / 16, ntn = c_out / 16;
+    std::vector<float> out((size_t)ngrp * ntaps * ntn * 256);
     size_t o = 0;
-    for (int c = 0; c < nchunk; ++c)
+    for (int kgg = 0; kgg < ngrp; ++kgg)
         for (int t = 0; t < ntaps; ++t)
-            for (int kg = 0; kg < nkg; ++kg)
-                for (int nt = 0; nt < ntn; ++nt)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int s = 0; s < 4; ++s)
-                            out[o++] = wget(16 * nt + (lane & 15), c * kc + 16 * kg + 4 * (lane >> 4) + s, t);
+            for (int nt = 0; nt < ntn; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s)
+                        out[o++] = wget(16 * nt + (lane & 15), 16 * kgg + 4 * (lane >> 4) + s, t);
     return out;
+}
+
+// Tiling policy: the MFMA/LDS/global-load mix of the conv loop reaches ~83 % of the fp32-MFMA rate with one
+// wave per SIMD and ~89 % with two (scripts/ubench/mfma_issue.hip), so take the 64-column tile when it still
+// puts two waves on every SIMD of the chip (256 CUs x 4 SIMDs x 2 = 2,048 waves) and the 32-column tile with a
+// 2-way K split (twice the workgroups, two per CU) below that.  Measured at B = 1,024: B 813k vs A 716k
+// step.agent/s; an 8-wave variant (32 columns, 4-way K split) was slower than B and is not built.
+bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
+    *g = l.g;
+    const long waves_a = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64) * 4;
+    auto set = [&](int kc, int nwn, int ks) { g->kc = kc; g->nwn = nwn; g->ks = ks; return true; };
+    static const char* force = getenv("CLD_TILING");            // experiments only: A / B
+    if (force && force[0] == 'A' && l.has_a) return set(32, 4, 1);
+    if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
+    if (l.has_a && (waves_a >= 2048 || !l.has_b)) return set(32, 4, 1);
+    if (l.has_b) return set(32, 2, 2);
+    return false;
 }
 
 struct Ws {
@@ -191,8 +213,12 @@ hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const flo
     a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
     if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
     a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
-    const bool timed = h->prof_on && l.g.l_in == 13 && l.g.ntaps == 5 && l.g.nwn == 4;   // one template instance
-    if (!timed) return launch_conv(l.g, a, b_pad, 0, s);
+    a.stamps = (h->stamp_buf && h->launch_counter == h->stamp_layer) ? h->stamp_buf : nullptr;
+    h->launch_counter++;
+    ConvGeom g;
+    if (!pick_tiling(l, b_pad, &g)) return hipErrorInvalidValue;
+    const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && l.c_out == 256;   // the dominant layer shape
+    if (!timed) return launch_conv(g, a, b_pad, 0, s);
     if (h->prof_used + 2 > h->prof_ev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t ev;
@@ -203,7 +229,7 @@ hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const flo
     }
     hipError_t e = hipEventRecord(h->prof_ev[h->prof_used], s);
     if (e != hipSuccess) return e;
-    e = launch_conv(l.g, a, b_pad, 0, s);
+    e = launch_conv(g, a, b_pad, 0, s);
     if (e != hipSuccess) return e;
     e = hipEventRecord(h->prof_ev[h->prof_used + 1], s);
     h->prof_used += 2;
@@ -216,6 +242,7 @@ hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const flo
 hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_pad, hipStream_t s) {
     const float* tbr = h->tb + (size_t)t_idx * NCB;
     float* const* b = w.buf;
+    h->launch_counter = 0;
     hipError_t e;
 #define RC(...) do { e = run_conv(h, __VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
     auto resblock = [&](const ResBlock& rb, const float* in1, const float* in2, float* out) -> hipError_t {
@@ -296,6 +323,13 @@ int cld_create(const cld_config* cfg, cld_handle* out) {
     return CLD_OK;
 }
 
+int cld_debug_stamps(cld_handle h, void* buf, int32_t layer) {
+    if (!h) return CLD_ERR_ARG;
+    h->stamp_buf = static_cast<unsigned long long*>(buf);
+    h->stamp_layer = layer;
+    return CLD_OK;
+}
+
 int cld_profile_enable(cld_handle h, int32_t on) {
     if (!h) return CLD_ERR_ARG;
     h->prof_on = on != 0;
@@ -366,8 +400,7 @@ int cld_finalize(cld_handle h, void* stream) {
                          int stride, int ntaps, const int* tapk, bool transposed, int off0, int orow0, int ostr,
                          int ly, int epi, const std::string& gn_name, int nwn) -> int {
         const std::vector<float>& W = *getw(h, wname + ".weight");
-        const int kc = (c1_real < 32 && c2 == 0) ? 16 : 32;
-        const int c1_pad = (c1_real + kc - 1) / kc * kc;
+        const int c1_pad = (c1_real + 31) / 32 * 32;     // the 4-channel latent is padded to one 32-channel chunk
         const int cin_real = c1_real + c2;
         const int kw = (int)(W.size() / ((size_t)c_out * cin_real));
         auto wget = [&](int co, int civ, int t) -> float {
@@ -378,7 +411,7 @@ int cld_finalize(cld_handle h, void* stream) {
             return transposed ? W[((size_t)ci * c_out + co) * kw + k]     // ConvTranspose1d [C_in, C_out, k]
                               : W[((size_t)co * cin_real + ci) * kw + k]; // Conv1d [C_out, C_in, k]
         };
-        std::vector<float> packed = pack_conv_weights(wget, c_out, c1_pad + c2, ntaps, kc);
+        std::vector<float> packed = pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
         UP(l.wfrag, packed);
         UP(l.bias, *getw(h, wname + ".bias"));
         if (epi == EPI_GN_MISH) {
@@ -386,8 +419,14 @@ int cld_finalize(cld_handle h, void* stream) {
             UP(l.beta, *getw(h, gn_name + ".bias"));
         }
         l.c_out = c_out; l.c1_real = c1_real; l.c1_pad = c1_pad; l.c2 = c2; l.ly = ly; l.off0 = off0; l.orow0 = orow0;
-        l.g = ConvGeom{L_in, lm, stride, ntaps, kc, nwn, epi, c_out / 8, ostr};
-        if (!conv_geom_supported(l.g))
+        (void)nwn;
+        l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0};
+        if (c2 > 0 && c2 != c1_real) return fail(h, CLD_ERR_ARG, "cld_finalize: concatenated sources must have equal channel counts");
+        ConvGeom t = l.g;
+        l.has_a = conv_geom_supported(t);
+        t.nwn = 2; t.ks = 2;
+        l.has_b = conv_geom_supported(t);
+        if (!l.has_a && !l.has_b)
             return fail(h, CLD_ERR_ARG, "cld_finalize: no kernel instance for layer '" + wname + "'");
         return CLD_OK;
     };

@@ -13,7 +13,9 @@ namespace cld {
 // One conv workgroup owns MT = 208 output rows (16 / 8 / 4 whole agents at
 // L = 13 / 26 / 52) x NT output channels and runs the implicit GEMM
 //     out[r, n] = sum_{tap, ci} X[in_row(r) + tap, ci] * W[tap][ci][n]
-// on v_mfma_f32_16x16x4_f32, 13 M-tiles x 1 N-tile per wave.
+// on v_mfma_f32_16x16x4_f32, 13 M-tiles x 1 N-tile per wave.  Two tilings exist per layer shape
+// (conv_block.hip: A = 64 columns / 4 waves, B = 32 columns / 4 waves with a 2-way K split);
+// pick_tiling() chooses by batch size so that every SIMD of the chip holds two waves.
 // ---------------------------------------------------------------------------
 constexpr int MT = 208;
 constexpr int NMT = 13;
@@ -40,6 +42,7 @@ struct ConvArgs {
     int ly;               // rows per agent of the OUTPUT tensor
     int off0;             // input row of tap 0 relative to STRIDE*j
     int orow0;            // output row = OSTR*j + orow0
+    unsigned long long* stamps;   // diagnostic builds (-DCLD_STAMPS) only: 16 u64 per workgroup; null otherwise
 };
 
 // A launcher picks the template instance from the geometry; returns hipError_t.
@@ -48,11 +51,13 @@ struct ConvGeom {
     int lm;       // GEMM rows per agent (output positions computed per agent)
     int stride;   // input row step per output position
     int ntaps;
-    int kc;       // K chunk (channels staged per step): 16 or 32
-    int nwn;      // N-tiles (16 cols) per workgroup: 4 (KS=1) or 2 (KS=2)
+    int kc;       // K chunk (channels staged per step): 32 or 64
+    int nwn;      // N-tiles (16 columns) per workgroup
+    int ks;       // K split across waves; the workgroup has nwn * ks waves
     int epi;
     int gs;       // GroupNorm group size (channels) = c_out / 8
     int ostr;     // output row stride (2 for the transposed conv halves)
+    int padc;     // 1: the input has fewer real channels than one K chunk (the 4-channel latent)
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, int grid_z_index, hipStream_t s);
 bool conv_geom_supported(const ConvGeom& g);

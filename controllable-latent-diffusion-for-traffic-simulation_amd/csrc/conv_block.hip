@@ -9,12 +9,16 @@
 // as an implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32: parity needs 1e-3
 // end to end and bf16 inputs miss it by 10x).
 //
-// Work decomposition (see cld_kernels.h): a 256-thread workgroup owns 208 GEMM
-// rows (whole agents) x NT = 16*NWN output channels; wave (nw, ks) owns 13
-// M-tiles x 1 N-tile and, when KS = 2, one half of every K chunk.  A workgroup
-// therefore always holds complete GroupNorm groups (all rows of an agent x whole
-// channel groups), so GroupNorm + Mish are fused into the epilogue with no
-// cross-workgroup reduction.
+// Work decomposition (see cld_kernels.h): a workgroup of NWN*KS waves owns 208 GEMM
+// rows (whole agents) x NT = 16*NWN output channels; wave (nw, ks) owns 13 M-tiles
+// x 1 N-tile and every KS-th 16-channel group of each K chunk.  A workgroup always
+// holds complete GroupNorm groups (all rows of an agent x whole channel groups), so
+// GroupNorm + Mish are fused into the epilogue with no cross-workgroup reduction.
+// Measured (scripts/ubench/mfma_issue.hip): with ONE wave per SIMD the MFMA /
+// ds_read / global_load mix of this loop tops out at ~83 % of the fp32-MFMA rate,
+// with TWO at ~89 %; the launcher therefore picks (NWN, KS) per layer and batch so
+// that every SIMD holds two waves (two 4-wave workgroups or one 8-wave workgroup
+// per CU), and register use is capped at 256 (launch bound 2 waves/SIMD).
 //
 //   A operand  : activations, channels-last in HBM, staged per K chunk (KC input
 //                channels) into a double-buffered LDS image whose rows carry a
@@ -41,35 +45,75 @@ __device__ __forceinline__ float mish_f(float x) {
     return x * n * __frcp_rn(n + 2.0f);
 }
 
+#ifdef CLD_STAMPS
+// diagnostic build: in-kernel cycle stamps (never compiled into the shipped library)
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (p.stamps && tid == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;               \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define STAMP_RT(k)                                                                                \
+    do {                                                                                           \
+        if (p.stamps && tid == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (k)] = t_;               \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#define STAMP_RT(k) do {} while (0)
+#endif
+
 template <int W> struct VecT;
 template <> struct VecT<4> { typedef v4f type; };
 template <> struct VecT<2> { typedef v2f type; };
+template <> struct VecT<1> { typedef float type; };
+template <int W> __device__ __forceinline__ float vget(const typename VecT<W>::type& v, int e) { return v[e]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int) { return v; }
+template <int W> __device__ __forceinline__ void vset(typename VecT<W>::type& v, int e, float x) { v[e] = x; }
+template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
 
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int EPI, int GS, int OSTR>
-__global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
-    constexpr int KS = 4 / NWN;            // K split across waves
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    // buffer_load_dwordx4 v, voff, rsrc, soff offen: the per-lane part of the address is a loop-invariant VGPR
+    // and everything that changes per chunk / iteration is a scalar -- no vector ALU work per load.
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// PADC: the input has fewer real channels than one K chunk (the 4-channel latent): zero-fill the rest.
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
+__global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const ConvArgs p) {
+    constexpr int NTHR = 64 * NWN * KS;
     constexpr int AG = MT / LM;            // agents per workgroup
     constexpr int LP = L_IN + 2;           // LDS rows per agent (2 halo rows shared with the neighbour)
     constexpr int AROWS = AG * LP + 2;
-    constexpr int KCP = KC + 4;            // padded LDS row, floats (keeps 16-B alignment)
+    constexpr int KCP = KC + 8;            // padded LDS row (floats): strides 40 / 72 make the b128 fragment reads of 16 consecutive rows conflict-free
     constexpr int ABUF = AROWS * KCP;      // floats per A image
     constexpr int ABUFP = ABUF + KCP;      // + one dump row for the staging pieces past the tile
     constexpr int NT = 16 * NWN;
     constexpr int OP = NT + 4;             // padded row of the output tile
     constexpr int NKG = KC / 16;           // 16-channel groups per chunk
     constexpr int KGW = NKG / KS;          // groups per wave per chunk
-    static_assert(NWN * KS == 4, "4 waves");
     static_assert(KGW >= 1 && KGW * KS == NKG, "K split must divide the chunk");
     static_assert(AG * LM == MT, "whole agents per tile");
     constexpr int IN_ROWS = AG * L_IN;
     constexpr int PPR = KC / 4;            // 16-byte pieces per staged row
     constexpr int NPC = IN_ROWS * PPR;
-    constexpr int NPIECE = (NPC + 255) / 256;
+    constexpr int NPIECE = (NPC + NTHR - 1) / NTHR;
     constexpr int NIT = NTAPS * KGW;       // (tap, group) iterations per chunk per wave
+    static_assert(NTHR % PPR == 0, "a thread keeps one channel piece");
 
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
+    STAMP(0);
+    STAMP_RT(8);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = wave % NWN;
@@ -79,36 +123,43 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
     const int ntn = p.c_out >> 4;
     const int nchunk = (p.c1_pad + p.c2) / KC;
 
-    // ---- staging map: piece i of this thread -> (global row, LDS offset) ------------------
+    // ---- staging map: piece i of this thread -> (byte offset in the tile's rows, LDS offset) ----
     // Every piece loads and stores unconditionally (no divergent branches, so the compiler can count
     // its vmcnt waits): pieces past the tile read this thread's piece 0 again and land in a dump row
-    // behind the image.
+    // behind the image.  Sources are buffer descriptors based at this workgroup's first row; the chunk's
+    // channel offset goes into the scalar offset of the load.
     const int pc4 = (tid % PPR) * 4;
+    const int stride1 = p.c1_real;                      // == p.c2 when a second source exists (host-checked)
+    const bool real = !PADC || pc4 < p.c1_real;
     int soff[NPIECE];
-    int grow[NPIECE];
+    int voff[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-        const int idx = tid + 256 * i;
+        const int idx = tid + NTHR * i;
         const bool ok = idx < NPC;
         const int r = ok ? idx / PPR : tid / PPR;
         const int a = r / L_IN;
         const int l = r - a * L_IN;
         soff[i] = ok ? (2 + a * LP + l) * KCP + pc4 : AROWS * KCP + pc4;
-        grow[i] = b0 * L_IN + r;
+        voff[i] = (r * stride1 + (real ? pc4 : 0)) * 4;
     }
+    const size_t tile_floats = (size_t)IN_ROWS * stride1;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x1) + (size_t)blockIdx.x * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x2 ? p.x2 : p.x1) + (size_t)blockIdx.x * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
     v4f st[NPIECE];
     auto load_chunk = [&](int c) {
         const int cv = c * KC;                          // virtual input channel of this chunk
-        const bool first = cv < p.c1_pad;               // wave-uniform: which source feeds the chunk
-        const float* src = first ? p.x1 : p.x2;
-        const int stride = first ? p.c1_real : p.c2;
-        int cb = (first ? cv : cv - p.c1_pad) + pc4;
-        const bool real = !first || cb < p.c1_real;     // only the 4-channel latent has a padded chunk
-        cb = real ? cb : 0;
+        if (cv < p.c1_pad) {                            // wave-uniform: which source feeds the chunk
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) {
-            const v4f v = *reinterpret_cast<const v4f*>(src + (size_t)grow[i] * stride + cb);
-            st[i] = real ? v : v4f{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NPIECE; ++i) {
+                const v4f v = buf_load16(rs1, voff[i], PADC ? 0 : cv * 4);
+                st[i] = real ? v : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) st[i] = buf_load16(rs2, voff[i], (cv - p.c1_pad) * 4);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -124,28 +175,30 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
         const int r = 16 * m + (lane & 15);
         const int a = r / LM;
         const int j = r - a * LM;
-        aoff[m] = (2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks;
+        aoff[m] = ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;   // bytes
     }
-    const float* wlane = p.wfrag + ((size_t)ntile_g * 64 + lane) * 4;
-    const size_t wstride = (size_t)ntn * 256;      // floats per (chunk, tap, group) slab
-    auto wptr = [&](int c, int it) {
-        const int t = it / KGW;
-        const int kg = ks + KS * (it % KGW);
-        return reinterpret_cast<const v4f*>(wlane + (size_t)((c * NTAPS + t) * NKG + kg) * wstride);
+    // B fragments: slab (16-channel group kgg, tap t) holds [ntn][64 lanes][4]; see pack_conv_weights
+    const int ngrp = (p.c1_pad + p.c2) >> 4;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.wfrag), 0, ngrp * NTAPS * ntn * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    auto wload = [&](int c, int it) {                   // `it` may run past the chunk
+        const int cc = c + it / NIT, ii = it % NIT;
+        const int t = ii / KGW;
+        const int kgg = cc * NKG + ks + KS * (ii % KGW);
+        return buf_load16(rsw, wlane, ((kgg * NTAPS + t) * ntn + ntile_g) * 1024);
     };
 
     v4f acc[NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: zero both images (halo rows stay zero for the whole kernel), stage chunk 0 ----
+    // ---- prologue: zero the halo rows of both images, stage chunk 0 ---------------------------
     load_chunk(0);
     // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them
-    auto wptr_lin = [&](int c, int it) { return wptr(c + it / NIT, it % NIT); };   // `it` may run past the chunk
-    v4f bq0 = *wptr(0, 0);
-    v4f bq1 = (1 / NIT < nchunk) ? *wptr_lin(0, 1) : bq0;
-    // zero the halo rows of both images: rows 0,1 and the 2 rows behind every agent
-    for (int i = tid; i < 2 * (AG + 1) * 2 * (KCP / 4); i += 256) {
+    v4f bq0 = wload(0, 0);
+    v4f bq1 = (1 / NIT < nchunk) ? wload(0, 1) : bq0;
+    for (int i = tid; i < 2 * (AG + 1) * 2 * (KCP / 4); i += NTHR) {
         const int q = i % (KCP / 4), hr = (i / (KCP / 4)) % (2 * (AG + 1)), buf = i / ((KCP / 4) * 2 * (AG + 1));
         const int g = hr >> 1;                          // gap index: 0 = leading rows, g>0 = behind agent g-1
         const int row = (g == 0 ? 0 : g * LP) + (hr & 1);
@@ -154,48 +207,119 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
     store_chunk(0);
     __syncthreads();
 
-    for (int c = 0; c < nchunk; ++c) {
-        const float* A = lds + (c & 1) * ABUFP;
-        const bool more = (c + 1 < nchunk);
-        v4f af[2][NMT];
+    STAMP(1);
+    // K loop.  Per chunk each wave runs NIT (tap, group) iterations of 52 MFMAs.  The A fragments of
+    // iteration it+1 are read from LDS while iteration it's MFMAs issue: one ds_read_b128 behind every
+    // 4th MFMA, pinned with sched_barrier so the reads are never bunched at the end of an iteration.
+    // The next chunk's image is written (and the workgroup barrier taken) before the LAST iteration of
+    // the current chunk, so that iteration prefetches the next chunk's first fragments: no fragment-load
+    // bubble at chunk boundaries either.  WAR: the image written at (c, NIT-2) was last read at
+    // (c-1, NIT-2), i.e. before the barrier of chunk c-1.
+    constexpr bool XPF = NIT >= 2;                 // cross-chunk fragment prefetch
+    constexpr int WIT = XPF ? NIT - 2 : 0;         // iteration after which the next image is written
+    constexpr int CUNR = 2;     // chunk pairs: image index and fragment-buffer parity are compile-time, so every
+                                // LDS fragment address is one loop-invariant VGPR + an immediate offset
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    v4f af[2][NMT];
 #pragma unroll
-        for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(A + aoff[m]);
+    for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m]);
+
+    for (int c0 = 0; c0 < nchunk; c0 += CUNR) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const v4f bcur = bq0;
-            bq0 = bq1;
-            if (c + (it + 2) / NIT < nchunk) bq1 = *wptr_lin(c, it + 2);
-            if (it == 0 && more) load_chunk(c + 1);      // next chunk's activations: in flight under this chunk's MFMAs
-            if (it + 1 < NIT) {
-                const int t1 = (it + 1) / KGW, g1 = (it + 1) % KGW;
+        for (int cu = 0; cu < CUNR; ++cu) {
+            const int c = c0 + cu;
+            if (c >= nchunk) break;
+            const int par = XPF ? (cu * NIT) & 1 : 0;  // fragment buffer holding this chunk's iteration 0
+            const int abase = cu * ABUFP * 4;          // bytes; chunk c lives in image c & 1 == cu
+            const int anext = (cu ^ 1) * ABUFP * 4;
+            const bool more = (c + 1 < nchunk);
+            if (!XPF && c > 0) {
 #pragma unroll
-                for (int m = 0; m < NMT; ++m)
-                    af[(it + 1) & 1][m] = *reinterpret_cast<const v4f*>(A + aoff[m] + t1 * KCP + 16 * KS * g1);
+                for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase);
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int it = 0; it < NIT; ++it) {
+                const int cur = (it + par) & 1;
+                const v4f bcur = bq0;
+                bq0 = bq1;
+                if (c + (it + 2) / NIT < nchunk) bq1 = wload(c, it + 2);
+                if (it == 0 && more) load_chunk(c + 1);      // next chunk's activations: in flight under this chunk's MFMAs
+                const bool in_chunk = it + 1 < NIT;
+                const bool fetch = in_chunk || (XPF && more);
+                const int src = in_chunk ? abase + (((it + 1) / KGW) * KCP + 16 * KS * ((it + 1) % KGW)) * 4 : anext;
 #pragma unroll
-                for (int m = 0; m < NMT; ++m)
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it & 1][m][s], bcur[s], acc[m], 0, 0, 0);
+                for (int g = 0; g < NMT; ++g) {
+                    if (fetch) af[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + aoff[g] + src);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int idx = 4 * g + q, sidx = idx / NMT, m = idx % NMT;
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][m][sidx], bcur[sidx], acc[m], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (it == WIT && more) {
+                    store_chunk(cu ^ 1);
+                    __syncthreads();
+                }
+            }
+#ifdef CLD_STAMPS
+            if (c < 3) STAMP(10 + c);
+#endif
         }
-        if (more) store_chunk((c + 1) & 1);
-        __syncthreads();
+    }
+    STAMP(2);
+
+    // ---- epilogue mapping: TPP lanes per (agent, group), 13 vectors of VW channels each --------
+    constexpr int VW = (16 * NT) / NTHR;
+    constexpr int NG = NT / GS;
+    constexpr int PAIRS = AG * NG;
+    constexpr int TPP = NTHR / PAIRS;
+    constexpr int VPR = GS / VW;
+    constexpr int RPI = TPP / VPR;
+    static_assert(VW >= 1 && PAIRS * TPP == NTHR && VPR * RPI == TPP && RPI * 13 == LM, "epilogue mapping");
+    typedef typename VecT<VW>::type vec_t;
+
+    const int pair = tid / TPP, q = tid % TPP;
+    const int a = pair / NG, g = pair % NG;
+    const int ch = g * GS + (q % VPR) * VW;          // channel within the tile
+    const int n = blockIdx.y * NT + ch;              // global output channel
+    const int jr = q / VPR;
+    const size_t obase = ((size_t)(b0 + a) * p.ly + (OSTR * jr + p.orow0)) * p.c_out + n;
+    const size_t ostep = (size_t)OSTR * RPI * p.c_out;
+
+    // epilogue operands are fetched now, so their latency hides under the tile exchange below
+    const vec_t bias = *reinterpret_cast<const vec_t*>(p.bias + n);
+    vec_t gam = bias, bet = bias, cbv = bias, tbv = bias;
+    if (EPI == EPI_GN_MISH) {
+        gam = *reinterpret_cast<const vec_t*>(p.gamma + n);
+        bet = *reinterpret_cast<const vec_t*>(p.beta + n);
+        if (p.cbias) cbv = *reinterpret_cast<const vec_t*>(p.cbias + (size_t)(b0 + a) * p.cb_stride + n);
+        if (p.tbias) tbv = *reinterpret_cast<const vec_t*>(p.tbias + n);
+    }
+    vec_t rv[13];
+    if (p.res) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) rv[i] = *reinterpret_cast<const vec_t*>(p.res + obase + i * ostep);
     }
 
-    // ---- epilogue: accumulators -> LDS tile [208][OP] (aliases the A images) -----------------
+    __syncthreads();               // every wave is done reading the images before the output tile overwrites them
+    STAMP(3);
+
+    // ---- accumulators -> LDS tile [208][OP] (aliases the A images), K-split partners add in turn ----
     float* O = lds;
     {
         const int col = nw * 16 + (lane & 15);
         const int rb = 4 * (lane >> 4);
-        if (KS == 1 || ks == 0) {
+        if (ks == 0) {
 #pragma unroll
             for (int m = 0; m < NMT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) O[(16 * m + rb + r) * OP + col] = acc[m][r];
         }
-        if (KS > 1) {
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
             __syncthreads();
-            if (ks == 1) {   // same element, same lane position of the partner wave: plain read-modify-write
+            if (ks == k) {   // same element, same lane position of the partner wave: plain read-modify-write
 #pragma unroll
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -204,31 +328,15 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
         }
     }
     __syncthreads();
-
-    // ---- per-(agent, group) epilogue: TPP lanes x 13 vectors of VW channels -----------------
-    constexpr int VW = NT / 16;
-    constexpr int NG = NT / GS;
-    constexpr int PAIRS = AG * NG;
-    constexpr int TPP = 256 / PAIRS;
-    constexpr int VPR = GS / VW;
-    constexpr int RPI = TPP / VPR;
-    static_assert(PAIRS * TPP == 256 && VPR * RPI == TPP && RPI * 13 == LM, "epilogue mapping");
-    typedef typename VecT<VW>::type vec_t;
-
-    const int pair = tid / TPP, q = tid % TPP;
-    const int a = pair / NG, g = pair % NG;
-    const int ch = g * GS + (q % VPR) * VW;          // channel within the tile
-    const int n = blockIdx.y * NT + ch;              // global output channel
-    const int jr = q / VPR;
+    STAMP(4);
 
     float v[13][VW];
-    const vec_t bias = *reinterpret_cast<const vec_t*>(p.bias + n);
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
         const int j = RPI * i + jr;
         const vec_t o = *reinterpret_cast<const vec_t*>(O + (a * LM + j) * OP + ch);
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[i][e] = o[e] + bias[e];
+        for (int e = 0; e < VW; ++e) v[i][e] = vget<VW>(o, e) + vget<VW>(bias, e);
     }
 
     if (EPI == EPI_GN_MISH) {
@@ -250,55 +358,42 @@ __global__ __launch_bounds__(256) void conv_block_kernel(const ConvArgs p) {
 #pragma unroll
         for (int o = 1; o < TPP; o <<= 1) ss += __shfl_xor(ss, o);
         const float rstd = 1.0f / sqrtf(ss * (1.0f / (float)(GS * LM)) + 1e-5f);
-        const vec_t gam = *reinterpret_cast<const vec_t*>(p.gamma + n);
-        const vec_t bet = *reinterpret_cast<const vec_t*>(p.beta + n);
-        float add[VW];
+        float add[VW], sc[VW], sh[VW];
 #pragma unroll
-        for (int e = 0; e < VW; ++e) add[e] = 0.f;
-        if (p.cbias) {
-            const vec_t cbv = *reinterpret_cast<const vec_t*>(p.cbias + (size_t)(b0 + a) * p.cb_stride + n);
-#pragma unroll
-            for (int e = 0; e < VW; ++e) add[e] += cbv[e];
-        }
-        if (p.tbias) {
-            const vec_t tbv = *reinterpret_cast<const vec_t*>(p.tbias + n);
-#pragma unroll
-            for (int e = 0; e < VW; ++e) add[e] += tbv[e];
+        for (int e = 0; e < VW; ++e) {
+            add[e] = (p.cbias ? vget<VW>(cbv, e) : 0.f) + (p.tbias ? vget<VW>(tbv, e) : 0.f);
+            sc[e] = rstd * vget<VW>(gam, e);
+            sh[e] = vget<VW>(bet, e);
         }
 #pragma unroll
         for (int i = 0; i < 13; ++i)
 #pragma unroll
-            for (int e = 0; e < VW; ++e)
-                v[i][e] = mish_f((v[i][e] - mean) * rstd * gam[e] + bet[e]) + add[e];
+            for (int e = 0; e < VW; ++e) v[i][e] = mish_f((v[i][e] - mean) * sc[e] + sh[e]) + add[e];
     }
 
+    STAMP(5);
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
-        const int j = RPI * i + jr;
-        const size_t idx = ((size_t)(b0 + a) * p.ly + (OSTR * j + p.orow0)) * p.c_out + n;
         vec_t o;
-        if (p.res) {
-            const vec_t rv = *reinterpret_cast<const vec_t*>(p.res + idx);
 #pragma unroll
-            for (int e = 0; e < VW; ++e) o[e] = v[i][e] + rv[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < VW; ++e) o[e] = v[i][e];
-        }
-        *reinterpret_cast<vec_t*>(p.y + idx) = o;
+        for (int e = 0; e < VW; ++e) vset<VW>(o, e, p.res ? v[i][e] + vget<VW>(rv[i], e) : v[i][e]);
+        *reinterpret_cast<vec_t*>(p.y + obase + i * ostep) = o;
     }
+    STAMP(6);
+    STAMP_RT(9);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int EPI, int GS, int OSTR>
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = MT / LM;
-    constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 4);   // image + dump row
-    constexpr int OTILE = MT * (16 * NWN + 4);     // the epilogue's output tile aliases the A images
+    constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);   // image + dump row
+    constexpr int OTILE = MT * (16 * NWN + 4);                   // the epilogue's output tile aliases the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
-    auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, EPI, GS, OSTR>;
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
+    auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -307,43 +402,62 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
         attr_done = true;
     }
     dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 1);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-#define CLD_CONV_INSTANCES(X)                        \
-    X(52, 52, 1, 5, 16, 4, EPI_GN_MISH, 8, 1)        \
-    X(52, 52, 1, 5, 32, 4, EPI_GN_MISH, 8, 1)        \
-    X(26, 26, 1, 5, 32, 4, EPI_GN_MISH, 16, 1)       \
-    X(13, 13, 1, 5, 32, 4, EPI_GN_MISH, 32, 1)       \
-    X(13, 13, 1, 5, 32, 2, EPI_GN_MISH, 16, 1)       \
-    X(26, 26, 1, 5, 32, 2, EPI_GN_MISH, 8, 1)        \
-    X(52, 52, 1, 1, 16, 4, EPI_BIAS, 8, 1)           \
-    X(26, 26, 1, 1, 32, 4, EPI_BIAS, 16, 1)          \
-    X(13, 13, 1, 1, 32, 4, EPI_BIAS, 32, 1)          \
-    X(13, 13, 1, 1, 32, 2, EPI_BIAS, 16, 1)          \
-    X(26, 26, 1, 1, 32, 2, EPI_BIAS, 8, 1)           \
-    X(52, 26, 2, 3, 32, 2, EPI_BIAS, 8, 1)           \
-    X(26, 13, 2, 3, 32, 2, EPI_BIAS, 16, 1)          \
-    X(13, 13, 1, 2, 32, 4, EPI_BIAS, 16, 2)          \
-    X(26, 26, 1, 2, 32, 4, EPI_BIAS, 8, 2)
+// (L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC)
+//   tilings: A = (KC 32, NWN 4, KS 1) 64 columns, 4 waves   -- large batches (>= 2 workgroups per CU anyway)
+//            B = (KC 32, NWN 2, KS 2) 32 columns, 4 waves   -- twice the workgroups of A
+//   (the template also supports 8-wave workgroups, e.g. KC 64 / NWN 2 / KS 4; measured slower than B, not built)
+#define CLD_CONV_INSTANCES(X)                            \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1)         \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1)         \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1)            \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1)            \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0)         \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0)         \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0)        \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0)        \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0)        \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0)        \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0)        \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0)        \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0)         \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0)         \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0)            \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0)            \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0)           \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0)           \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0)           \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0)           \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0)           \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0)           \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0)            \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0)            \
+    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0)            \
+    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0)           \
+    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0)           \
+    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0)           \
+    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0)            \
+    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0)
 
-static inline bool geom_is(const ConvGeom& g, int l_in, int lm, int stride, int ntaps, int kc, int nwn,
-                           int epi, int gs, int ostr) {
+static inline bool geom_is(const ConvGeom& g, int l_in, int lm, int stride, int ntaps, int kc, int nwn, int ks,
+                           int epi, int gs, int ostr, int padc) {
     return g.l_in == l_in && g.lm == lm && g.stride == stride && g.ntaps == ntaps && g.kc == kc &&
-           g.nwn == nwn && g.epi == epi && g.gs == gs && g.ostr == ostr;
+           g.nwn == nwn && g.ks == ks && g.epi == epi && g.gs == gs && g.ostr == ostr && g.padc == padc;
 }
 
 bool conv_geom_supported(const ConvGeom& g) {
-#define X(a, b, c, d, e, f, h, i, j) if (geom_is(g, a, b, c, d, e, f, h, i, j)) return true;
+#define X(a, b, c, d, e, f, k, h, i, j, l) if (geom_is(g, a, b, c, d, e, f, k, h, i, j, l)) return true;
     CLD_CONV_INSTANCES(X)
 #undef X
     return false;
 }
 
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, int /*grid_z_index*/, hipStream_t s) {
-#define X(a_, b_, c_, d_, e_, f_, h_, i_, j_) \
-    if (geom_is(g, a_, b_, c_, d_, e_, f_, h_, i_, j_)) return launch_inst<a_, b_, c_, d_, e_, f_, h_, i_, j_>(a, b_pad, s);
+#define X(a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_) \
+    if (geom_is(g, a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_)) return launch_inst<a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_>(a, b_pad, s);
     CLD_CONV_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -149,6 +149,10 @@ int cld_decode(cld_handle h, const float* z, const float* cond, const float* cur
 int cld_profile_enable(cld_handle h, int32_t on);
 int cld_profile_read(cld_handle h, double* total_ms /*HOST*/, int64_t* launches /*HOST*/, double* total_flop /*HOST*/);
 
+/* Diagnostic builds only (-DCLD_STAMPS; a no-op in the shipped library): conv launch number `layer`
+ * (0..36) of every following U-Net evaluation writes 16 u64 cycle stamps per workgroup into `buf`. */
+int cld_debug_stamps(cld_handle h, void* buf /*DEVICE, u64[16 * workgroups]*/, int32_t layer);
+
 /* Library build id (for the "native code loaded" check). */
 const char* cld_version(void);
 
