@@ -215,7 +215,9 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     // the current chunk, so that iteration prefetches the next chunk's first fragments: no fragment-load
     // bubble at chunk boundaries either.  WAR: the image written at (c, NIT-2) was last read at
     // (c-1, NIT-2), i.e. before the barrier of chunk c-1.
-    constexpr bool XPF = NIT >= 2;                 // cross-chunk fragment prefetch
+    constexpr bool LEAN = STRIDE == 2;             // stride-2 tiles stage twice the rows (13 pieces/thread): keep ONE
+                                                   // fragment buffer there and let the partner wave cover the LDS latency
+    constexpr bool XPF = NIT >= 2 && !LEAN;        // cross-chunk fragment prefetch
     constexpr int WIT = XPF ? NIT - 2 : 0;         // iteration after which the next image is written
     constexpr int CUNR = 2;     // chunk pairs: image index and fragment-buffer parity are compile-time, so every
                                 // LDS fragment address is one loop-invariant VGPR + an immediate offset
@@ -233,19 +235,24 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
             const int abase = cu * ABUFP * 4;          // bytes; chunk c lives in image c & 1 == cu
             const int anext = (cu ^ 1) * ABUFP * 4;
             const bool more = (c + 1 < nchunk);
-            if (!XPF && c > 0) {
+            if (!XPF && !LEAN && c > 0) {
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase);
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int cur = (it + par) & 1;
+                const int cur = LEAN ? 0 : (it + par) & 1;
+                if (LEAN && !(c == 0 && it == 0)) {
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m)
+                        af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase + ((it / KGW) * KCP + 16 * KS * (it % KGW)) * 4);
+                }
                 const v4f bcur = bq0;
                 bq0 = bq1;
                 if (c + (it + 2) / NIT < nchunk) bq1 = wload(c, it + 2);
                 if (it == 0 && more) load_chunk(c + 1);      // next chunk's activations: in flight under this chunk's MFMAs
                 const bool in_chunk = it + 1 < NIT;
-                const bool fetch = in_chunk || (XPF && more);
+                const bool fetch = !LEAN && (in_chunk || (XPF && more));
                 const int src = in_chunk ? abase + (((it + 1) / KGW) * KCP + 16 * KS * ((it + 1) % KGW)) * 4 : anext;
 #pragma unroll
                 for (int g = 0; g < NMT; ++g) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (it == WIT && more) {
+                if (it == (LEAN ? NIT - 1 : WIT) && more) {
                     store_chunk(cu ^ 1);
                     __syncthreads();
                 }
@@ -305,27 +312,19 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     __syncthreads();               // every wave is done reading the images before the output tile overwrites them
     STAMP(3);
 
-    // ---- accumulators -> LDS tile [208][OP] (aliases the A images), K-split partners add in turn ----
+    // ---- accumulators -> LDS tiles [KS][208][OP] (aliasing the A images): every K-split rank stores its own
+    //      partial tile, one barrier, and the epilogue threads add the KS partials while reading ----
     float* O = lds;
+    constexpr int OTILE = MT * OP;
+    static_assert(KS * OTILE <= 2 * ABUFP, "partial output tiles must fit in the A images");
     {
         const int col = nw * 16 + (lane & 15);
         const int rb = 4 * (lane >> 4);
-        if (ks == 0) {
+        float* Ok = O + ks * OTILE;
 #pragma unroll
-            for (int m = 0; m < NMT; ++m)
+        for (int m = 0; m < NMT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) O[(16 * m + rb + r) * OP + col] = acc[m][r];
-        }
-#pragma unroll
-        for (int k = 1; k < KS; ++k) {
-            __syncthreads();
-            if (ks == k) {   // same element, same lane position of the partner wave: plain read-modify-write
-#pragma unroll
-                for (int m = 0; m < NMT; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) O[(16 * m + rb + r) * OP + col] += acc[m][r];
-            }
-        }
+            for (int r = 0; r < 4; ++r) Ok[(16 * m + rb + r) * OP + col] = acc[m][r];
     }
     __syncthreads();
     STAMP(4);
@@ -337,6 +336,12 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
         const vec_t o = *reinterpret_cast<const vec_t*>(O + (a * LM + j) * OP + ch);
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[i][e] = vget<VW>(o, e) + vget<VW>(bias, e);
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {      // K-split partials, added in rank order
+            const vec_t ok = *reinterpret_cast<const vec_t*>(O + k * OTILE + (a * LM + j) * OP + ch);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[i][e] += vget<VW>(ok, e);
+        }
     }
 
     if (EPI == EPI_GN_MISH) {
@@ -390,7 +395,7 @@ template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int 
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = MT / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);   // image + dump row
-    constexpr int OTILE = MT * (16 * NWN + 4);                   // the epilogue's output tile aliases the A images
+    constexpr int OTILE = KS * MT * (16 * NWN + 4);              // the epilogue's partial output tiles alias the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC>;
