@@ -114,7 +114,7 @@ def main():
         if launches > 0 and ms > 0:
             ach = flop / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
                     "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0> (Conv1d k5 -> 256 ch + GroupNorm + Mish at L=13; "
                                "7 launches/step with 256 input channels, 1 with 128; tiling picked by batch size)"
                                % ("4,1" if (B + 15) // 16 * 4 * 4 >= 2048 else "2,2")),
@@ -147,6 +147,22 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+    gfx950 correction + WRITE_SIZE, profiles/pmc_quick.sh); PMC cannot be collected inside this process, so
+    the number is the committed one for the same kernel and batch size, else null."""
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+            with open(f) as fh:
+                t = json.load(fh)
+            if int(t.get("batch_agents", -1)) == B:
+                return int(t["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
 
 
 def host_cores():
@@ -185,7 +201,7 @@ def cpu_baseline(B):
         t0 = time.perf_counter()
         O.ddpm_step(w, s, x, cond, 99, z)                    # probe: sizes the bounded sample (~12 s of CPU work)
         probe = time.perf_counter() - t0
-        CPU_STEPS = max(1, min(8, int(12.0 / max(probe, 1e-3))))
+        CPU_STEPS = max(1, min(60, int(12.0 / max(probe, 1e-3))))
         t0 = time.perf_counter()
         for k in range(CPU_STEPS):
             x, _, _ = O.ddpm_step(w, s, x, cond, 98 - k, z)
