@@ -206,6 +206,29 @@ Ws carve(void* ws, int b_pad) {
 }
 inline int pad16(int b) { return (b + 15) / 16 * 16; }
 
+ConvArgs make_args(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
+                   const float* cb, const float* tb_row) {
+    ConvArgs a{};
+    a.x1 = x1; a.x2 = x2; a.c1_real = l.c1_real; a.c1_pad = l.c1_pad; a.c2 = l.c2;
+    a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
+    if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
+    a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
+    a.stamps = nullptr;
+    (void)h;
+    return a;
+}
+
+// two independent layers with one grid shape -> one launch (conv_pair_kernel); falls back to two launches
+hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const ConvLayer& lb, const ConvArgs& ab,
+                    int b_pad, hipStream_t s) {
+    ConvGeom ga, gb;
+    if (!pick_tiling(la, b_pad, &ga) || !pick_tiling(lb, b_pad, &gb)) return hipErrorInvalidValue;
+    h->launch_counter += 2;
+    if (ga.nwn == gb.nwn && conv_pair_supported(ga, gb)) return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
+    hipError_t e = launch_conv(ga, aa, b_pad, 0, s);
+    return e != hipSuccess ? e : launch_conv(gb, ab, b_pad, 0, s);
+}
+
 hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
                     const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
     ConvArgs a{};
@@ -247,8 +270,14 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
 #define RC(...) do { e = run_conv(h, __VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
     auto resblock = [&](const ResBlock& rb, const float* in1, const float* in2, float* out) -> hipError_t {
         const float* r = in1;           // identity residual reads the block input
-        if (rb.has_res) { RC(rb.res, in1, in2, b[0], nullptr); r = b[0]; }
-        RC(rb.c0, in1, in2, b[1], nullptr);
+        if (rb.has_res) {               // first conv and 1x1 projection both read only the block input: one launch
+            e = run_pair(h, rb.c0, make_args(h, rb.c0, in1, in2, b[1], nullptr, w.cb, tbr),
+                         rb.res, make_args(h, rb.res, in1, in2, b[0], nullptr, w.cb, tbr), b_pad, s);
+            if (e != hipSuccess) return e;
+            r = b[0];
+        } else {
+            RC(rb.c0, in1, in2, b[1], nullptr);
+        }
         RC(rb.c1, b[1], nullptr, out, r);
         return hipSuccess;
     };
@@ -265,12 +294,14 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     RB(h->blocks[7], b[2], nullptr, b[3]);
     RB(h->blocks[8], b[3], b[5], b[2]);               // cat(x, skip) 512@13 -> 128@13
     RB(h->blocks[9], b[2], nullptr, b[6]);
-    RC(h->upT[0][0], b[6], nullptr, b[3], nullptr);
-    RC(h->upT[0][1], b[6], nullptr, b[3], nullptr);   // 128@26
+    e = run_pair(h, h->upT[0][0], make_args(h, h->upT[0][0], b[6], nullptr, b[3], nullptr, w.cb, tbr),
+                 h->upT[0][1], make_args(h, h->upT[0][1], b[6], nullptr, b[3], nullptr, w.cb, tbr), b_pad, s);   // 128@26
+    if (e != hipSuccess) return e;
     RB(h->blocks[10], b[3], b[4], b[2]);              // cat(x, skip) 256@26 -> 64@26
     RB(h->blocks[11], b[2], nullptr, b[6]);
-    RC(h->upT[1][0], b[6], nullptr, b[3], nullptr);
-    RC(h->upT[1][1], b[6], nullptr, b[3], nullptr);   // 64@52
+    e = run_pair(h, h->upT[1][0], make_args(h, h->upT[1][0], b[6], nullptr, b[3], nullptr, w.cb, tbr),
+                 h->upT[1][1], make_args(h, h->upT[1][1], b[6], nullptr, b[3], nullptr, w.cb, tbr), b_pad, s);   // 64@52
+    if (e != hipSuccess) return e;
     RC(h->final_cb, b[3], nullptr, b[7], nullptr);
 #undef RB
 #undef RC

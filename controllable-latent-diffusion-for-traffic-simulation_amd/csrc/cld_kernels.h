@@ -61,6 +61,9 @@ struct ConvGeom {
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, int grid_z_index, hipStream_t s);
 bool conv_geom_supported(const ConvGeom& g);
+// two independent convolutions with the same grid shape in ONE launch (blockIdx.z picks the role)
+hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s);
+bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
 
 // ---------------------------------------------------------------------------
 // small kernels (misc_kernels.hip)

@@ -88,7 +88,7 @@ __device__ __forceinline__ v4f buf_load16(__amdgpu_buffer_rsrc_t r, int voff, in
 
 // PADC: the input has fewer real channels than one K chunk (the 4-channel latent): zero-fill the rest.
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
-__global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const int bx, const int by) {
     constexpr int NTHR = 64 * NWN * KS;
     constexpr int AG = MT / LM;            // agents per workgroup
     constexpr int LP = L_IN + 2;           // LDS rows per agent (2 halo rows shared with the neighbour)
@@ -109,8 +109,6 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     constexpr int NIT = NTAPS * KGW;       // (tap, group) iterations per chunk per wave
     static_assert(NTHR % PPR == 0, "a thread keeps one channel piece");
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
     const int tid = threadIdx.x;
     STAMP(0);
     STAMP_RT(8);
@@ -118,8 +116,8 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = wave % NWN;
     const int ks = wave / NWN;
-    const int b0 = blockIdx.x * AG;
-    const int ntile_g = blockIdx.y * NWN + nw;
+    const int b0 = bx * AG;
+    const int ntile_g = by * NWN + nw;
     const int ntn = p.c_out >> 4;
     const int nchunk = (p.c1_pad + p.c2) / KC;
 
@@ -145,9 +143,9 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     }
     const size_t tile_floats = (size_t)IN_ROWS * stride1;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x1) + (size_t)blockIdx.x * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
+        const_cast<float*>(p.x1) + (size_t)bx * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x2 ? p.x2 : p.x1) + (size_t)blockIdx.x * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
+        const_cast<float*>(p.x2 ? p.x2 : p.x1) + (size_t)bx * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
     v4f st[NPIECE];
     auto load_chunk = [&](int c) {
         const int cv = c * KC;                          // virtual input channel of this chunk
@@ -289,7 +287,7 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     const int pair = tid / TPP, q = tid % TPP;
     const int a = pair / NG, g = pair % NG;
     const int ch = g * GS + (q % VPR) * VW;          // channel within the tile
-    const int n = blockIdx.y * NT + ch;              // global output channel
+    const int n = by * NT + ch;              // global output channel
     const int jr = q / VPR;
     const size_t obase = ((size_t)(b0 + a) * p.ly + (OSTR * jr + p.orow0)) * p.c_out + n;
     const size_t ostep = (size_t)OSTR * RPI * p.c_out;
@@ -388,6 +386,27 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
     STAMP_RT(9);
 }
 
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
+__global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC>(p, lds, blockIdx.x, blockIdx.y);
+}
+
+// Two launches that do not depend on each other and share a grid shape, merged into one: blockIdx.z picks the
+// role.  Used for a residual block's first conv (k5 + GroupNorm + Mish) next to its 1x1 residual projection
+// (both read only the block input), and for the two output-parity halves of a transposed conv.  Saves the
+// dependent-launch boundary (~1.4 us each, 7 per U-Net evaluation); the per-workgroup prologue/epilogue cost is
+// NOT saved -- the second role's workgroups still form their own generation on each CU.
+struct ConvPairArgs { ConvArgs a, b; };
+template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC,
+          int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B>
+__global__ __launch_bounds__(64 * NWN * KS, 2) void conv_pair_kernel(const ConvPairArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (interleaving the two roles along x, alone or in XCD-balanced groups of 8, measured 9 % slower end to end)
+    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC>(p.a, lds, blockIdx.x, blockIdx.y);
+    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC>(p.b, lds, blockIdx.x, blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
@@ -409,6 +428,69 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 1);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_bytes, s, a);
     return hipGetLastError();
+}
+
+template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B>
+static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_pad, hipStream_t s) {
+    constexpr int AG = MT / LM;
+    constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);
+    constexpr int OTILE = KS * MT * (16 * NWN + 4);
+    constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
+    auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    ConvPairArgs pa{a, b};
+    dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 2);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_bytes, s, pa);
+    return hipGetLastError();
+}
+
+// pairs: (L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B), stride 1 on both sides
+#define CLD_PAIR_INSTANCES(X)                                         \
+    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
+    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
+    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
+    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
+    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
+    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
+    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
+    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
+    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
+    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
+    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)           \
+    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)           \
+    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)            \
+    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)
+
+static inline bool pair_is(const ConvGeom& a, const ConvGeom& b, int l_in, int lm, int kc, int nwn, int ks, int gs, int ostr,
+                           int padc, int ntaps_a, int epi_a, int ntaps_b, int epi_b) {
+    auto common = [&](const ConvGeom& g) {
+        return g.l_in == l_in && g.lm == lm && g.stride == 1 && g.kc == kc && g.nwn == nwn && g.ks == ks && g.gs == gs &&
+               g.ostr == ostr && g.padc == padc;
+    };
+    return common(a) && common(b) && a.ntaps == ntaps_a && a.epi == epi_a && b.ntaps == ntaps_b && b.epi == epi_b;
+}
+
+bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b) {
+#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12) if (pair_is(a, b, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12)) return true;
+    CLD_PAIR_INSTANCES(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s) {
+    if (a.c_out != b.c_out) return hipErrorInvalidValue;
+#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12) \
+    if (pair_is(ga, gb, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12)) \
+        return launch_pair_inst<c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12>(a, b, b_pad, s);
+    CLD_PAIR_INSTANCES(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 // (L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC)
