@@ -129,16 +129,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     const int pc4 = (tid % PPR) * 4;
     const int stride1 = p.c1_real;                      // == p.c2 when a second source exists (host-checked)
     const bool real = !PADC || pc4 < p.c1_real;
-    int soff[NPIECE];
     int voff[NPIECE];
 #pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
+    for (int i = 0; i < NPIECE; ++i) {                  // global side first: only shifts, so the loads issue early
         const int idx = tid + NTHR * i;
-        const bool ok = idx < NPC;
-        const int r = ok ? idx / PPR : tid / PPR;
-        const int a = r / L_IN;
-        const int l = r - a * L_IN;
-        soff[i] = ok ? (2 + a * LP + l) * KCP + pc4 : AROWS * KCP + pc4;
+        const int r = (idx < NPC) ? idx / PPR : tid / PPR;
         voff[i] = (r * stride1 + (real ? pc4 : 0)) * 4;
     }
     const size_t tile_floats = (size_t)IN_ROWS * stride1;
@@ -160,21 +155,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
             for (int i = 0; i < NPIECE; ++i) st[i] = buf_load16(rs2, voff[i], (cv - p.c1_pad) * 4);
         }
     };
-    auto store_chunk = [&](int buf) {
-        float* A = lds + buf * ABUFP;
-#pragma unroll
-        for (int i = 0; i < NPIECE; ++i) *reinterpret_cast<v4f*>(A + soff[i]) = st[i];
-    };
 
-    // ---- A fragment offsets: lane (i = lane&15, kk = lane>>4) of M-tile m --------------------
-    int aoff[NMT];
-#pragma unroll
-    for (int m = 0; m < NMT; ++m) {
-        const int r = 16 * m + (lane & 15);
-        const int a = r / LM;
-        const int j = r - a * LM;
-        aoff[m] = ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;   // bytes
-    }
     // B fragments: slab (16-channel group kgg, tap t) holds [ntn][64 lanes][4]; see pack_conv_weights
     const int ngrp = (p.c1_pad + p.c2) >> 4;
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
@@ -187,15 +168,39 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         return buf_load16(rsw, wlane, ((kgg * NTAPS + t) * ntn + ntile_g) * 1024);
     };
 
-    v4f acc[NMT];
-#pragma unroll
-    for (int m = 0; m < NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: zero the halo rows of both images, stage chunk 0 ---------------------------
+    // ---- prologue: chunk 0 and the first weight fragments go out first; the LDS-side address arithmetic
+    //      (divisions by the row counts), the accumulator clear and the halo zeroing run under their latency ----
     load_chunk(0);
     // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them
     v4f bq0 = wload(0, 0);
     v4f bq1 = (1 / NIT < nchunk) ? wload(0, 1) : bq0;
+    __builtin_amdgcn_sched_barrier(0);                  // keep the loads ahead of the arithmetic below
+    int soff[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int idx = tid + NTHR * i;
+        const bool ok = idx < NPC;
+        const int r = ok ? idx / PPR : tid / PPR;
+        const int a = r / L_IN;
+        const int l = r - a * L_IN;
+        soff[i] = ok ? (2 + a * LP + l) * KCP + pc4 : AROWS * KCP + pc4;
+    }
+    int aoff[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+        const int r = 16 * m + (lane & 15);
+        const int a = r / LM;
+        const int j = r - a * LM;
+        aoff[m] = ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;   // bytes
+    }
+    v4f acc[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
+    auto store_chunk = [&](int buf) {
+        float* A = lds + buf * ABUFP;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) *reinterpret_cast<v4f*>(A + soff[i]) = st[i];
+    };
     for (int i = tid; i < 2 * (AG + 1) * 2 * (KCP / 4); i += NTHR) {
         const int q = i % (KCP / 4), hr = (i / (KCP / 4)) % (2 * (AG + 1)), buf = i / ((KCP / 4) * 2 * (AG + 1));
         const int g = hr >> 1;                          // gap index: 0 = leading rows, g>0 = behind agent g-1
