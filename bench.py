@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=32, help="scenes per GPU")
     ap.add_argument("--agents", type=int, default=32, help="agents per scene")
     ap.add_argument("--denoise-steps", type=int, default=100)
+    ap.add_argument("--cfg-w", type=float, default=0.0,
+                    help="classifier-free guidance weight (BASELINE configs[2]: --agents 64 --cfg-w 2.0); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     args = ap.parse_args()
@@ -75,12 +77,13 @@ def main():
     cond = torch.randn(B, 256, device=dev, generator=g)
     x_T = torch.randn(B, 52, 4, device=dev, generator=g)
     noise = torch.randn(n, B, 52, 4, device=dev, generator=g)
+    non_cond = torch.randn(B, 256, device=dev, generator=g) if args.cfg_w != 0.0 else None
     cs = torch.zeros(B, 4, device=dev)
     cs[:, 2] = torch.rand(B, device=dev, generator=g) * 15.0
     gathered = torch.empty(world * B, 52, 6, device=dev) if distributed else None
 
     def one_step():
-        x0, x1, logp = eng.sample(x_T, cond, noise=noise)
+        x0, x1, logp = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w)
         traj = eng.decode(x0, cond, cs, descaled_output=True)
         if distributed:
             gather_trajectories(traj, gathered)
@@ -128,14 +131,18 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: 32 scenes x 32 agents per GPU, 100 denoising steps "
-                               "(DDPM ancestral loop of the reference), latent seq 52 x 4, cond 256, CFG off; "
+        "config": {"workload": ("BASELINE configs[1]" if (args.scenes, args.agents, args.cfg_w) == (32, 32, 0.0) else "custom")
+                               + f": {args.scenes} scenes x {args.agents} agents per GPU, {n} denoising steps "
+                               "(DDPM ancestral loop of the reference), latent seq 52 x 4, cond 256, "
+                               + (f"CFG w={args.cfg_w} (2 U-Net passes per step)" if args.cfg_w else "CFG off") + "; "
                                "+ LSTM decode + unicycle roll-out" + ("; RCCL all-gather of trajectories" if distributed else ""),
                    "scenes_per_gpu": args.scenes, "agents_per_scene": args.agents, "agents_per_gpu": B,
-                   "denoise_steps": n, "weights": "random init (synth seed 0)"},
+                   "denoise_steps": n, "cfg_guidance_w": args.cfg_w, "unet_passes_per_step": 2 if args.cfg_w else 1,
+                   "weights": "random init (synth seed 0)"},
         "scenes_per_s": round(world * args.scenes * args.steps / dt, 2),
-        "unet_tflops_effective": round(value * FLOP_PER_STEP_AGENT / 1e12, 2),
-        "roofline_whole_path_frac": round(value * FLOP_PER_STEP_AGENT / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+        "unet_tflops_effective": round(value * FLOP_PER_STEP_AGENT * (2 if args.cfg_w else 1) / 1e12, 2),
+        "roofline_whole_path_frac": round(value * FLOP_PER_STEP_AGENT * (2 if args.cfg_w else 1) / 1e12
+                                          / (PEAK_F32_MFMA_TFLOPS * world), 4),
     }
     if roof:
         out["roofline"] = roof

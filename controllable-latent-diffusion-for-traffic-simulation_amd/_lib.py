@@ -41,6 +41,7 @@ SIGNATURES = {
     "cld_unet_forward": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_ddpm_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.c_size_t, _P]),
     "cld_sample": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
+    "cld_sample_cfg": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
     "cld_log_prob": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_lstm_decode": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
     "cld_action_to_state": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),

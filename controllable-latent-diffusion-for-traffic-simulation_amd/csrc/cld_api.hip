@@ -679,6 +679,47 @@ int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* 
     return CLD_OK;
 }
 
+int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
+                   float guidance_w, int32_t steps, float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_sample_cfg", 2 * pad16(B), 0, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x_T || !cond || !non_cond) return fail(h, CLD_ERR_ARG, "cld_sample_cfg: null pointer");
+    if (steps != h->cfg.n_timesteps)
+        return fail(h, CLD_ERR_ARG, "cld_sample_cfg: steps must equal n_timesteps (the reference sampler has stride 1)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // one 2B-agent batch per step: rows [0, bp) carry cond_feat, rows [bp, 2bp) the unconditional features,
+    // both halves the same latent; the head combines the two noise predictions and rewrites both halves.
+    const int bp = pad16(B), bp2 = 2 * bp;
+    Ws w = carve(workspace, bp2);
+    float* x_hi = w.xw + (size_t)bp * T * D;
+    HIPCK(h, launch_pack_latent(x_T, w.xw, B, bp, s));
+    HIPCK(h, launch_pack_latent(x_T, x_hi, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    HIPCK(h, launch_cond_bias(non_cond, h->wc, h->cbias_b, w.cb + (size_t)bp * NCB, B, bp, NCB, s));
+    for (int it = 0; it < steps; ++it) {
+        const int i = steps - 1 - it;
+        HIPCK(h, run_unet(h, w, w.xw, i, bp2, s));
+        const float sigma = std::exp(0.5f * h->plvc[i]);
+        HeadArgs a{};
+        a.f = w.buf[7]; a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w;
+        a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
+        a.z = noise ? noise + (size_t)it * B * T * D : nullptr;
+        a.seed = seed; a.step_salt = (unsigned long long)it;
+        a.x_out = w.xw; a.x_out2 = x_hi;
+        a.mean_out = (i == 0) ? w.meanb : nullptr;
+        a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
+        a.sg = (i == 0) ? 0.f : sigma;
+        HIPCK(h, launch_head(a, s));
+        if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
+        if (i == 0) {
+            if (x0) HIPCK(h, launch_unpack(w.xw, x0, B, s));
+            if (logp) HIPCK(h, launch_logprob(w.xw, w.meanb, sigma, logp, B, s));
+        }
+    }
+    return CLD_OK;
+}
+
 int cld_log_prob(cld_handle h, const float* x_t, const float* x_tm1, const float* cond, int32_t t_idx, float* out,
                  int32_t M, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_common(h, "cld_log_prob", M, t_idx, workspace, workspace_bytes);

@@ -84,6 +84,9 @@ struct HeadArgs {
     float* mean_out;     // [B_pad,52,4] or null
     float* x_out;        // [B_pad,52,4] or null (may alias x)
     float xc, nc, sg;
+    float cfg_w;         // classifier-free guidance: eps = (1 + w) eps_cond - w eps_uncond when f_uncond != null
+    const float* f_uncond;   // [B_pad,52,64] final-block activations of the unconditional pass, or null
+    float* x_out2;       // second copy of x' (the unconditional half of the next step's 2B batch), or null
     unsigned long long seed;   // on-device RNG (z == null and sg != 0)
     unsigned long long step_salt;
     int B, b_pad;

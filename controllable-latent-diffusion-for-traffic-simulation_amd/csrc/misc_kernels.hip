@@ -118,6 +118,23 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     v4f eps;
 #pragma unroll
     for (int d = 0; d < 4; ++d) eps[d] = e[d] + bb[d];
+    if (a.f_uncond) {   // classifier-free guidance in noise space (upstream diffuser.py:787)
+        const v4f* g4 = reinterpret_cast<const v4f*>(a.f_uncond + (size_t)row * 64);
+        float u[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const v4f f = g4[k4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                u[d] = fmaf(f[0], w[d][4 * k4 + 0], u[d]);
+                u[d] = fmaf(f[1], w[d][4 * k4 + 1], u[d]);
+                u[d] = fmaf(f[2], w[d][4 * k4 + 2], u[d]);
+                u[d] = fmaf(f[3], w[d][4 * k4 + 3], u[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) eps[d] = (1.0f + a.cfg_w) * eps[d] - a.cfg_w * (u[d] + bb[d]);
+    }
     if (a.eps_out && real) reinterpret_cast<v4f*>(a.eps_out)[row] = eps;
     if (!a.mean_out && !a.x_out) return;
     const v4f x = reinterpret_cast<const v4f*>(a.x)[row];
@@ -144,6 +161,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) xn[d] = mean[d] + a.sg * z[d];
         reinterpret_cast<v4f*>(a.x_out)[row] = xn;
+        if (a.x_out2) reinterpret_cast<v4f*>(a.x_out2)[row] = xn;
     }
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {

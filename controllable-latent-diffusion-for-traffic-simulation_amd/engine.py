@@ -134,7 +134,10 @@ class Engine:
                                                C.byref(sigma), B, ws, wsn, self._stream()), "cld_ddpm_step")
         return xn, mean, float(sigma.value)
 
-    def sample(self, x_T, cond, noise=None, seed: int = 0, want_x1=True, want_logp=True):
+    def sample(self, x_T, cond, noise=None, seed: int = 0, want_x1=True, want_logp=True,
+               non_cond=None, guidance_w: float = 0.0):
+        """Full ancestral loop.  With `non_cond` [B,256] and guidance_w != 0: classifier-free guidance
+        (eps = (1+w) eps_cond - w eps_uncond, upstream diffuser.py:787), both passes as one 2B batch per step."""
         x_T = self._f32(x_T)
         B = x_T.shape[0]
         x_T = self._f32(x_T, (B, T, D)); cond = self._f32(cond, (B, COND))
@@ -143,10 +146,18 @@ class Engine:
         x0 = torch.empty_like(x_T)
         x1 = torch.empty_like(x_T) if want_x1 else None
         logp = torch.empty(B, dtype=torch.float32, device=self.device) if want_logp else None
-        ws, wsn = self._workspace(B)
+        cfg = non_cond is not None and guidance_w != 0.0
         with torch.cuda.device(self.device):
-            self._check(self.lib.cld_sample(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), n, _ptr(x0), _ptr(x1),
-                                            _ptr(logp), B, C.c_uint64(seed), ws, wsn, self._stream()), "cld_sample")
+            if cfg:
+                non_cond = self._f32(non_cond, (B, COND))
+                ws, wsn = self._workspace(2 * ((B + 15) // 16 * 16))
+                self._check(self.lib.cld_sample_cfg(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), _ptr(non_cond),
+                                                    C.c_float(guidance_w), n, _ptr(x0), _ptr(x1), _ptr(logp), B,
+                                                    C.c_uint64(seed), ws, wsn, self._stream()), "cld_sample_cfg")
+            else:
+                ws, wsn = self._workspace(B)
+                self._check(self.lib.cld_sample(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), n, _ptr(x0), _ptr(x1),
+                                                _ptr(logp), B, C.c_uint64(seed), ws, wsn, self._stream()), "cld_sample")
         return x0, x1, logp
 
     def log_prob(self, x_t, x_tm1, cond, t_idx: int):

@@ -119,6 +119,16 @@ int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* 
                float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* cld_sample with classifier-free guidance.  CLD's DmModel has no CFG branch; the definition is the vendored
+ * upstream DiffuserModel.p_mean_variance (src/tbsim/models/diffuser.py:766-789): a second U-Net pass on
+ * aux_info['non_cond_feat'] (features of a map raster filled with -1, diffuser.py:390-411,459-471) and
+ * eps = (1 + w) * eps_cond - w * eps_uncond, then the same DDPM update.  non_cond [B,256]; both passes run as
+ * one 2B-agent batch per step; the workspace must cover 2 * (B rounded up to 16) agents
+ * (cld_workspace_bytes(h, 2 * ((B + 15) / 16 * 16))).  Other arguments as cld_sample. */
+int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
+                   float guidance_w, int32_t steps, float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* out = DmModel.log_prob(x_t, x_{t-1}, aux_info, t)  (dm_model.py:165-174):
  * mean over (T, D) of log N(x_{t-1}; mean(x_t, eps), sigma_t).  Forward only. */
 int cld_log_prob(cld_handle h, const float* x_t, const float* x_tm1, const float* cond, int32_t t_idx,

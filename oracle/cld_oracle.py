@@ -186,6 +186,25 @@ def sample(w, sched, x_T: Tensor, noise: Tensor, cond: Tensor, n_steps: Optional
     return out
 
 
+def sample_cfg(w, sched, x_T: Tensor, noise: Tensor, cond: Tensor, non_cond: Tensor, guidance_w: float) -> dict:
+    """Classifier-free-guided chain.  Not in CLD's DmModel; defined by the vendored upstream
+    DiffuserModel.p_mean_variance, src/tbsim/models/diffuser.py:766-789: a second U-Net pass on
+    aux_info['non_cond_feat'] and eps = (1 + w) eps_cond - w eps_uncond, then the DDPM update of
+    dm_model.py:144-163 in the loop of dm_model.py:119-132."""
+    n = int(sched["x_t_cof"].shape[0])
+    x, x1 = x_T, None
+    dt = x.dtype
+    for s, i in enumerate(reversed(range(n))):
+        t = torch.full((x.shape[0],), i, dtype=torch.long)
+        eps = (1 + guidance_w) * unet_forward(w, x, cond, t) - guidance_w * unet_forward(w, x, non_cond, t)
+        mean = sched["x_t_cof"][i].to(dt) * x - sched["noise_cof"][i].to(dt) * eps
+        sigma = (0.5 * sched["posterior_log_variance_clipped"][i].to(dt)).exp()
+        x = mean + ((0.0 if i == 0 else 1.0) * sigma) * noise[s]
+        if i == 1:
+            x1 = x.clone()
+    return {"pred_traj": x, "x1": x1}
+
+
 def log_prob(w, sched, x_t: Tensor, x_tm1: Tensor, cond: Tensor, i: int) -> Tensor:
     """dm_model.py:165-174 -- log N(x_{t-1}; mean(x_t, eps), sigma_t) averaged over (T, D)."""
     B = x_t.shape[0]

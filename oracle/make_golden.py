@@ -83,11 +83,43 @@ def save(name, meta, **arrays):
     print(f"{name}: {os.path.getsize(path)/1024:.1f} KB  {[ (k, v.shape) for k, v in arrays.items()]}")
 
 
+def section_cfg(ref):
+    """Classifier-free-guided chain.  CLD's DmModel has no CFG sampler; the fixture composes the REFERENCE's own
+    U-Net (dm.model, two passes) and posterior (dm.x_tminus1_mean_var) with the upstream combination
+    eps = (1 + w) eps_cond - w eps_uncond (src/tbsim/models/diffuser.py:787) and the loop of dm_model.py:119-132."""
+    n, B, wgt = 10, 8, 2.0
+    dm = build_dm(ref, n, True)
+    inp = synth.make_inputs(B, IN_SEED)
+    cond = T(inp["cond_feat"])
+    non_cond = T(synth.normal(IN_SEED, "non_cond_feat", (B, 256)))
+    nz = synth.make_noise(B, n, NOISE_SEED)
+    x = T(nz["x_T"])
+    x1 = None
+    with torch.no_grad():
+        for s_, i in enumerate(reversed(range(n))):
+            t = torch.full((B,), i, dtype=torch.long)
+            e_c = dm.model(x, {"cond_feat": cond}, t)
+            e_u = dm.model(x, {"cond_feat": non_cond}, t)
+            eps = (1 + wgt) * e_c - wgt * e_u
+            mean, logvar = dm.x_tminus1_mean_var(x, eps, t)
+            sigma = (0.5 * logvar).exp()
+            x = mean + (0.0 if i == 0 else 1.0) * sigma * T(nz["noise"][s_])
+            if i == 1:
+                x1 = x.clone()
+    save("sample_cfg_n10", {"B": B, "n_timesteps": n, "w_seed": W_SEED, "affine_jitter": True, "in_seed": IN_SEED,
+                            "noise_seed": NOISE_SEED, "guidance_w": wgt, "non_cond": "normal(in_seed,'non_cond_feat')"},
+         pred_traj=x, x1=x1)
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
     ref = _refimport.load()
     algo = ref.algo
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg":      # regenerate only the newer fixture(s)
+        section_cfg(ref)
+        return
+    section_cfg(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

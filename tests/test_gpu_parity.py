@@ -103,6 +103,27 @@ def test_full_chain_golden(golden, n, jitter):
     assert np.allclose(logp.cpu().numpy(), g["log_prob_final"], atol=1e-4)
 
 
+def test_cfg_chain_golden(golden):
+    """classifier-free guidance (w = 2): two U-Net passes per step batched as one 2B launch set."""
+    meta, g = golden("sample_cfg_n10")
+    B, n = meta["B"], meta["n_timesteps"]
+    e = _engine(n, True, decoder=False)
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    non_cond = torch.from_numpy(synth.normal(meta["in_seed"], "non_cond_feat", (B, 256)))
+    nz = synth.make_noise(B, n, meta["noise_seed"])
+    x0, x1, _ = e.sample(torch.from_numpy(nz["x_T"]), cond, noise=torch.from_numpy(nz["noise"]),
+                         non_cond=non_cond, guidance_w=meta["guidance_w"])
+    for got, k in ((x0, "pred_traj"), (x1, "x1")):
+        scale = float(np.abs(g[k]).max())
+        err = float(np.abs(got.cpu().numpy() - g[k]).max())
+        print(f"cfg chain {k}: max|d|={err:.3e} max|ref|={scale:.3e}")
+        assert err <= 1e-3 * scale
+    # w = 0 with a non_cond given must reproduce the plain chain bit for bit (same kernels, same order)
+    a, _, _ = e.sample(torch.from_numpy(nz["x_T"]), cond, noise=torch.from_numpy(nz["noise"]))
+    b, _, _ = e.sample(torch.from_numpy(nz["x_T"]), cond, noise=torch.from_numpy(nz["noise"]), non_cond=non_cond, guidance_w=0.0)
+    assert torch.equal(a, b)
+
+
 def test_log_prob_golden(golden, eng_jitter):
     meta, g = golden("log_prob")
     B = meta["B"]

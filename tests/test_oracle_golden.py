@@ -90,6 +90,19 @@ def test_full_chain(golden, n, jitter):
     assert np.allclose(g["log_prob_final"], 22.106914, atol=1e-4)
 
 
+def test_cfg_chain(golden):
+    meta, g = golden("sample_cfg_n10")
+    B, n = meta["B"], meta["n_timesteps"]
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    non_cond = torch.from_numpy(synth.normal(meta["in_seed"], "non_cond_feat", (B, 256)))
+    nz = synth.make_noise(B, n, meta["noise_seed"])
+    out = O.sample_cfg(W(True), O.schedule(n), torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"]), cond,
+                       non_cond, meta["guidance_w"])
+    for k in ("pred_traj", "x1"):
+        scale = float(np.abs(g[k]).max())
+        assert float(np.abs(out[k].numpy() - g[k]).max()) <= 1e-4 * scale
+
+
 def test_log_prob(golden):
     meta, g = golden("log_prob")
     B = meta["B"]
