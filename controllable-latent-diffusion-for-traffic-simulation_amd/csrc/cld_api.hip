@@ -57,6 +57,8 @@ struct cld_handle_s {
     ConvLayer down[2], upT[2][2], final_cb;
     float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr;
     DecoderWeights dec{};
+    EncoderWeights enc{};
+    bool has_encoder = false;
     DynParams dyn{};
     // optional HIP-event timing of the dominant conv kernel instance (k5 GN+Mish block -> 256 channels, L = 13)
     bool prof_on = false;
@@ -120,6 +122,14 @@ void add_expect(cld_handle h) {
     e["lstm_dec.lstm.bias_ih_l1"] = 256;        e["lstm_dec.lstm.bias_hh_l1"] = 256;
     e["lstm_dec.cond2hidden.weight"] = 64 * 256; e["lstm_dec.cond2hidden.bias"] = 64;
     e["lstm_dec.hid2act.weight"] = 2 * 64;       e["lstm_dec.hid2act.bias"] = 2;
+    // encoder + latent heads (lstm_vae.py:6-19,82-83)
+    e["lstm_enc.lstm.weight_ih_l0"] = 256 * 6;  e["lstm_enc.lstm.weight_hh_l0"] = 256 * 64;
+    e["lstm_enc.lstm.bias_ih_l0"] = 256;        e["lstm_enc.lstm.bias_hh_l0"] = 256;
+    e["lstm_enc.lstm.weight_ih_l1"] = 256 * 64; e["lstm_enc.lstm.weight_hh_l1"] = 256 * 64;
+    e["lstm_enc.lstm.bias_ih_l1"] = 256;        e["lstm_enc.lstm.bias_hh_l1"] = 256;
+    e["lstm_enc.cond2hidden.weight"] = 64 * 256; e["lstm_enc.cond2hidden.bias"] = 64;
+    e["mu.weight"] = 4 * 64;     e["mu.bias"] = 4;
+    e["logvar.weight"] = 4 * 64; e["logvar.bias"] = 4;
 }
 
 // dm_model.py:29-56 + diffuser_helpers.py:451-462, same op order in fp32
@@ -573,6 +583,32 @@ int cld_finalize(cld_handle h, void* stream) {
         UP(tmp, *getw(h, "lstm_dec.hid2act.weight")); h->dec.w_h2a = tmp;
         UP(tmp, *getw(h, "lstm_dec.hid2act.bias")); h->dec.b_h2a = tmp;
     }
+    // ---- encoder (optional) ---------------------------------------------------------------
+    h->has_encoder = true;
+    for (const auto& kv : h->expect)
+        if ((kv.first.rfind("lstm_enc.", 0) == 0 || kv.first.rfind("mu.", 0) == 0 || kv.first.rfind("logvar.", 0) == 0) &&
+            !h->w.count(kv.first))
+            h->has_encoder = false;
+    if (h->has_encoder) {
+        float* tmp;
+        UP(tmp, *getw(h, "lstm_enc.lstm.weight_ih_l0")); h->enc.w_ih0 = tmp;
+        UP(tmp, *getw(h, "lstm_enc.lstm.weight_hh_l0")); h->enc.w_hh0 = tmp;
+        UP(tmp, *getw(h, "lstm_enc.lstm.weight_ih_l1")); h->enc.w_ih1 = tmp;
+        UP(tmp, *getw(h, "lstm_enc.lstm.weight_hh_l1")); h->enc.w_hh1 = tmp;
+        std::vector<float> b0(256), b1(256);
+        for (int i = 0; i < 256; ++i) {
+            b0[i] = (*getw(h, "lstm_enc.lstm.bias_ih_l0"))[i] + (*getw(h, "lstm_enc.lstm.bias_hh_l0"))[i];
+            b1[i] = (*getw(h, "lstm_enc.lstm.bias_ih_l1"))[i] + (*getw(h, "lstm_enc.lstm.bias_hh_l1"))[i];
+        }
+        UP(tmp, b0); h->enc.b0 = tmp;
+        UP(tmp, b1); h->enc.b1 = tmp;
+        UP(tmp, *getw(h, "lstm_enc.cond2hidden.weight")); h->enc.w_c2h = tmp;
+        UP(tmp, *getw(h, "lstm_enc.cond2hidden.bias")); h->enc.b_c2h = tmp;
+        UP(tmp, *getw(h, "mu.weight")); h->enc.w_mu = tmp;
+        UP(tmp, *getw(h, "mu.bias")); h->enc.b_mu = tmp;
+        UP(tmp, *getw(h, "logvar.weight")); h->enc.w_lv = tmp;
+        UP(tmp, *getw(h, "logvar.bias")); h->enc.b_lv = tmp;
+    }
 #undef UP
     HIPCK(h, hipStreamSynchronize(s));     // host staging vectors die with this scope
     h->w.clear();
@@ -763,6 +799,25 @@ int cld_decode(cld_handle h, const float* z, const float* cond, const float* cur
     if (!z || !cond || !curr_states || !traj || B < 1) return fail(h, CLD_ERR_ARG, "cld_decode: bad argument");
     HIPCK(h, launch_decode(h->dec, h->dyn, z, cond, curr_states, act_out, traj, B, descaled_output,
                            static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const float* noise, float* z, float* mu,
+               float* logvar, int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!h->finalized || !h->has_encoder) return fail(h, CLD_ERR_STATE, "cld_traj2z: encoder weights not loaded");
+    if (!x6_scaled || !cond || B < 1 || (!z && !mu && !logvar)) return fail(h, CLD_ERR_ARG, "cld_traj2z: bad argument");
+    HIPCK(h, launch_encode(h->enc, x6_scaled, cond, noise, z, mu, logvar, B, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+int cld_state_to_state_and_action(cld_handle h, const float* positions, const float* yaws, const float* curr_speed,
+                                  float* out6, int32_t B, int32_t scaled_output, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!positions || !yaws || !curr_speed || !out6 || B < 1)
+        return fail(h, CLD_ERR_ARG, "cld_state_to_state_and_action: bad argument");
+    HIPCK(h, launch_state_to_state_action(h->dyn, positions, yaws, curr_speed, out6, B, scaled_output,
+                                          static_cast<hipStream_t>(stream)));
     return CLD_OK;
 }
 

@@ -113,4 +113,20 @@ hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const floa
 hipError_t launch_action_to_state(const DynParams& d, const float* act, const float* cs, float* traj,
                                   int B, int scaled_input, int descaled_output, hipStream_t s);
 
+
+// ---- VAE encoder (models/vae/lstm_vae.py:6-26,87-99) ---------------------------------------------------
+struct EncoderWeights {   // device pointers, reference layouts
+    const float *w_ih0, *w_hh0, *b0;   // [256,6] [256,64] [256] (b_ih + b_hh)
+    const float *w_ih1, *w_hh1, *b1;   // [256,64] [256,64] [256]
+    const float *w_c2h, *b_c2h;        // [64,256] [64]
+    const float *w_mu, *b_mu;          // [4,64] [4]
+    const float *w_lv, *b_lv;          // [4,64] [4]
+};
+// x6 [B,52,6] (scaled state+action), cond [B,256], noise [B,52,4] or null -> z, mu, logvar [B,52,4] (any may be null)
+hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* cond, const float* noise,
+                         float* z, float* mu, float* logvar, int B, hipStream_t s);
+// positions [B,52,2], yaws [B,52,1], curr_speed [B] -> [B,52,6] = (x, y, v, yaw, acc, yaw-rate), optionally scaled
+hipError_t launch_state_to_state_action(const DynParams& d, const float* pos, const float* yaw, const float* speed,
+                                        float* out6, int B, int scaled_output, hipStream_t s);
+
 }  // namespace cld

@@ -322,4 +322,122 @@ hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const floa
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// convert_state_to_state_and_action (src/tbsim/models/diffuser_helpers.py:685-749): finite differences of
+// (x, y, yaw) under the unicycle model, positions/yaw pre-padded with zeros, speed with curr_speed.
+__global__ void state_to_state_action_kernel(const DynParams d, const float* __restrict__ pos, const float* __restrict__ yaw,
+                                             const float* __restrict__ speed, float* __restrict__ out, int B, int scaled) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float px = 0.f, py = 0.f, pyaw = 0.f, pv = speed[b];
+    const float two_pi = 6.283185307179586f;
+    for (int t = 0; t < 52; ++t) {
+        const float x = pos[((size_t)b * 52 + t) * 2], y = pos[((size_t)b * 52 + t) * 2 + 1], th = yaw[(size_t)b * 52 + t];
+        const float v = (x - px) / d.dt * cosf(th) + (y - py) / d.dt * sinf(th);
+        const float acc = (v - pv) / d.dt;
+        float df = th - pyaw + 0.5f * two_pi;                 // angle_diff: floored modulo into [-pi, pi)
+        df = df - floorf(df / two_pi) * two_pi - 0.5f * two_pi;
+        if (df > 3.141592653589793f) df -= two_pi;
+        const float yr = df / d.dt;
+        float o[6] = {x, y, v, th, acc, yr};
+        if (scaled) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o[k] = (o[k] - d.mean[k]) / d.std[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[((size_t)b * 52 + t) * 6 + k] = o[k];
+        px = x; py = y; pyaw = th; pv = v;
+    }
+}
+hipError_t launch_state_to_state_action(const DynParams& d, const float* pos, const float* yaw, const float* speed,
+                                        float* out6, int B, int scaled_output, hipStream_t s) {
+    hipLaunchKernelGGL(state_to_state_action_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d, pos, yaw, speed, out6, B,
+                       scaled_output);
+    return hipGetLastError();
+}
+
+// LSTM encoder + (mu, logvar) heads + reparametrisation (lstm_vae.py:6-26,87-99): same structure as the decoder
+// kernel -- thread r owns gate row r of both layers (6 + 64 + 64 + 64 weights in registers), state in LDS.
+__global__ __launch_bounds__(256) void encode_kernel(const EncoderWeights w, const float* __restrict__ x6,
+                                                     const float* __restrict__ cond, const float* __restrict__ noise,
+                                                     float* __restrict__ z, float* __restrict__ mu_out,
+                                                     float* __restrict__ lv_out, int B) {
+    __shared__ __attribute__((aligned(16))) float h0[64], h1[64], c0[64], c1[64], gates[256], xin[312], head[8 * 52];
+    __shared__ __attribute__((aligned(16))) float condm[256];
+    const int r = threadIdx.x;
+    float wi0[6], wh0[64], wi1[64], wh1[64];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wi0[k] = w.w_ih0[r * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        wh0[k] = w.w_hh0[r * 64 + k];
+        wi1[k] = w.w_ih1[r * 64 + k];
+        wh1[k] = w.w_hh1[r * 64 + k];
+    }
+    const float bias0 = w.b0[r], bias1 = w.b1[r];
+    const int gate = r >> 6;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        condm[r] = cond[(size_t)b * 256 + r];
+        for (int i = r; i < 312; i += 256) xin[i] = x6[(size_t)b * 312 + i];
+        __syncthreads();
+        if (r < 64) {
+            float s = w.b_c2h[r];
+            const float* wr = w.w_c2h + r * 256;
+            for (int k = 0; k < 256; ++k) s = fmaf(condm[k], wr[k], s);
+            h0[r] = s; h1[r] = s; c0[r] = 0.f; c1[r] = 0.f;
+        }
+        __syncthreads();
+        for (int t = 0; t < 52; ++t) {
+            float g = bias0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g = fmaf(xin[6 * t + k], wi0[k], g);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g = fmaf(h0[k], wh0[k], g);
+            gates[r] = (gate == 2) ? tanhf(g) : sigmoid_f(g);
+            __syncthreads();
+            if (r < 64) {
+                const float c = gates[64 + r] * c0[r] + gates[r] * gates[128 + r];
+                c0[r] = c;
+                h0[r] = gates[192 + r] * tanhf(c);
+            }
+            __syncthreads();
+            g = bias1;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g = fmaf(h0[k], wi1[k], g);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) g = fmaf(h1[k], wh1[k], g);
+            gates[r] = (gate == 2) ? tanhf(g) : sigmoid_f(g);
+            __syncthreads();
+            if (r < 64) {
+                const float c = gates[64 + r] * c1[r] + gates[r] * gates[128 + r];
+                c1[r] = c;
+                h1[r] = gates[192 + r] * tanhf(c);
+            }
+            __syncthreads();
+            if (r < 8) {   // mu (rows 0-3) and logvar (rows 4-7) heads on the top layer's output
+                const float* wr = (r < 4 ? w.w_mu + r * 64 : w.w_lv + (r - 4) * 64);
+                float s = (r < 4 ? w.b_mu[r] : w.b_lv[r - 4]);
+                for (int k = 0; k < 64; ++k) s = fmaf(h1[k], wr[k], s);
+                head[8 * t + r] = s;
+            }
+        }
+        __syncthreads();
+        if (r < 208) {
+            const int t = r >> 2, k = r & 3;
+            const float m = head[8 * t + k], lv = head[8 * t + 4 + k];
+            if (mu_out) mu_out[(size_t)b * 208 + r] = m;
+            if (lv_out) lv_out[(size_t)b * 208 + r] = lv;
+            if (z) z[(size_t)b * 208 + r] = m + (noise ? noise[(size_t)b * 208 + r] : 0.f) * expf(0.5f * lv);
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* cond, const float* noise, float* z,
+                         float* mu, float* logvar, int B, hipStream_t s) {
+    const int grid = B < 2048 ? B : 2048;
+    hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(256), 0, s, w, x6, cond, noise, z, mu, logvar, B);
+    return hipGetLastError();
+}
+
 }  // namespace cld

@@ -202,6 +202,29 @@ class Engine:
                                             int(descaled_output), self._stream()), "cld_decode")
         return (traj, act) if want_act else traj
 
+    def traj2z(self, x6_scaled, cond, noise=None):
+        """LSTMVAE.traj2z: -> (z, mu, logvar), each [B,52,4]."""
+        x = self._f32(x6_scaled)
+        B = x.shape[0]
+        x = self._f32(x, (B, T, 6)); cond = self._f32(cond, (B, COND))
+        noise = None if noise is None else self._f32(noise, (B, T, D))
+        z, mu, lv = (torch.empty(B, T, D, dtype=torch.float32, device=self.device) for _ in range(3))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_traj2z(self._h, _ptr(x), _ptr(cond), _ptr(noise), _ptr(z), _ptr(mu), _ptr(lv), B,
+                                            self._stream()), "cld_traj2z")
+        return z, mu, lv
+
+    def state_to_state_and_action(self, positions, yaws, curr_speed, scaled_output=False):
+        p = self._f32(positions)
+        B = p.shape[0]
+        p = self._f32(p, (B, T, 2)); y = self._f32(yaws, (B, T, 1)); v = self._f32(curr_speed, (B,))
+        out = torch.empty(B, T, 6, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_state_to_state_and_action(self._h, _ptr(p), _ptr(y), _ptr(v), _ptr(out), B,
+                                                               int(scaled_output), self._stream()),
+                        "cld_state_to_state_and_action")
+        return out
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on: bool = True):
         self._check(self.lib.cld_profile_enable(self._h, int(on)), "cld_profile_enable")

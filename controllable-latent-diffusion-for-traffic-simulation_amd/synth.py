@@ -148,6 +148,41 @@ def decoder_shapes(latent=LATENT, hidden=HIDDEN, cond=COND) -> "OrderedDict[str,
     return s
 
 
+def encoder_shapes(hidden=HIDDEN, cond=COND, latent=LATENT) -> "OrderedDict[str, tuple]":
+    """`lstm_enc.*`, `mu.*`, `logvar.*` entries of LSTMVAE (lstm_vae.py:6-19,82-83)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    g = 4 * hidden
+    s["lstm_enc.lstm.weight_ih_l0"] = (g, 6)
+    s["lstm_enc.lstm.weight_hh_l0"] = (g, hidden)
+    s["lstm_enc.lstm.bias_ih_l0"] = (g,)
+    s["lstm_enc.lstm.bias_hh_l0"] = (g,)
+    s["lstm_enc.lstm.weight_ih_l1"] = (g, hidden)
+    s["lstm_enc.lstm.weight_hh_l1"] = (g, hidden)
+    s["lstm_enc.lstm.bias_ih_l1"] = (g,)
+    s["lstm_enc.lstm.bias_hh_l1"] = (g,)
+    s["lstm_enc.cond2hidden.weight"] = (hidden, cond)
+    s["lstm_enc.cond2hidden.bias"] = (hidden,)
+    s["mu.weight"] = (latent, hidden)
+    s["mu.bias"] = (latent,)
+    s["logvar.weight"] = (latent, hidden)
+    s["logvar.bias"] = (latent,)
+    return s
+
+
+def make_encoder_weights(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
+    shapes = encoder_shapes()
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in shapes.items():
+        if ".lstm." in name:
+            bound = 1.0 / np.sqrt(HIDDEN)
+        elif name.endswith(".weight"):
+            bound = 1.0 / np.sqrt(shape[1])
+        else:
+            bound = 1.0 / np.sqrt(shapes[name[: -len("bias")] + "weight"][1])
+        out[name] = uniform(seed, name, shape, -bound, bound)
+    return out
+
+
 def _fan_in(name: str, shape: tuple) -> int:
     if name.endswith(".2.conv.weight") and ".ups." in name:
         # ConvTranspose1d: PyTorch computes fan_in from dim 1 of [C_in, C_out, k]
@@ -200,6 +235,23 @@ def make_inputs(B: int, seed: int = 1) -> dict:
     cs = np.zeros((B, 4), np.float32)
     cs[:, 2] = uniform(seed, "curr_speed", (B,), 0.0, 15.0)
     return {"cond_feat": cond, "curr_states": cs}
+
+
+def make_future(B: int, seed: int = 1) -> dict:
+    """Synthetic ground-truth futures for the encoder path: a unicycle roll-out with smooth random controls in
+    the agent frame -> target_positions [B,52,2], target_yaws [B,52,1], curr_speed [B]."""
+    dt = 0.1
+    v0 = uniform(seed, "fut_speed", (B,), 0.0, 15.0).astype(np.float64)
+    acc = np.cumsum(normal(seed, "fut_acc", (B, HORIZON)).astype(np.float64) * 0.3, axis=1)
+    yr = np.cumsum(normal(seed, "fut_yr", (B, HORIZON)).astype(np.float64) * 0.05, axis=1)
+    yr[0] = 2.5          # one agent spins through +-pi so the yaw wrap of angle_diff is exercised
+    v = np.clip(v0[:, None] + np.cumsum(acc * dt, axis=1), 0.0, 30.0)
+    yaw = np.cumsum(yr * dt, axis=1)
+    yaw = (yaw + np.pi) % (2 * np.pi) - np.pi
+    x = np.cumsum(v * np.cos(yaw) * dt, axis=1)
+    y = np.cumsum(v * np.sin(yaw) * dt, axis=1)
+    return {"target_positions": np.stack((x, y), axis=-1).astype(np.float32),
+            "target_yaws": yaw[..., None].astype(np.float32), "curr_speed": v0.astype(np.float32)}
 
 
 def make_noise(B: int, steps: int, seed: int = 123) -> dict:

@@ -3,7 +3,7 @@
 `VaeModel.convert_action_to_state_and_action / scale_traj / descale_traj`
 (models/vae/vae_model.py:100-173), as used at
 src/trainers/guide_dm_trainer.py:97-98,195-196,210-211.
-The encoder (`traj2z`) and `ContextEncoder` are "next" rows and not built.
+`traj2z` (the encoder) is built too; `ContextEncoder` (f-1) is not.
 """
 from __future__ import annotations
 
@@ -21,6 +21,13 @@ class LSTMVAE:
 
     def lstm_dec(self, z, context):
         return self.engine.lstm_decode(z, context)
+
+    def traj2z(self, x, context, noise=None):
+        """lstm_vae.py:87-99 -> (z, mean, logvar).  `noise` replaces the reference's randn_like draw (:97);
+        drawn from torch's device generator when omitted."""
+        if noise is None:
+            noise = torch.randn(x.shape[0], 52, 4, device=self.engine.device)
+        return self.engine.traj2z(x, context, noise)
 
 
 class VaeModel:
@@ -46,6 +53,12 @@ class VaeModel:
             x_out = x_out.reshape(B * N, T, -1)
         out = self.engine.action_to_state(x_out, curr_states, scaled_input, descaled_output)
         return out.reshape(B, N, T, -1) if four_d else out
+
+    def get_state_and_action_from_data_batch(self, batch, scaled=False):
+        """models/context_utils.py:64-70 (+ scale_traj when `scaled`): future (x, y, yaw) + curr_speed ->
+        [B,52,6] = (x, y, v, yaw, acc, yaw-rate)."""
+        return self.engine.state_to_state_and_action(batch["target_positions"][:, :52], batch["target_yaws"][:, :52],
+                                                     batch["curr_speed"], scaled_output=scaled)
 
     def scale_traj(self, traj, chosen_inds=()):
         inds = list(chosen_inds) or self.default_chosen_inds      # (x - mean) / std, vae_model.py:152

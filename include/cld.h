@@ -150,6 +150,19 @@ int cld_action_to_state(cld_handle h, const float* act, const float* curr_states
 int cld_decode(cld_handle h, const float* z, const float* cond, const float* curr_states,
                float* traj, float* act_out, int32_t B, int32_t descaled_output, void* stream);
 
+/* z, mu, logvar = LSTMVAE.traj2z(x, context)  (models/vae/lstm_vae.py:87-99; encoder :6-26): 2-layer LSTM(6->64)
+ * with h0 = cond2hidden(context), mu / logvar heads 64->4, z = mu + noise * exp(0.5 * logvar).
+ * x6_scaled [B,52,6] = scaled (x, y, v, yaw, acc, yaw-rate); noise [B,52,4] is the caller's randn_like draw
+ * (lstm_vae.py:97; NULL -> z = mu); outputs [B,52,4], any may be NULL.  Weights: "lstm_enc.*", "mu.*", "logvar.*". */
+int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const float* noise, float* z, float* mu,
+               float* logvar, int32_t B, void* stream);
+
+/* convert_state_to_state_and_action(traj_state, vel_init, dt)  (src/tbsim/models/diffuser_helpers.py:685-749) as
+ * called by get_state_and_action_from_data_batch (models/context_utils.py:64-70): positions [B,52,2], yaws [B,52,1],
+ * curr_speed [B] -> [B,52,6]; scaled_output != 0 also applies VaeModel.scale_traj (vae_model.py:131-155). */
+int cld_state_to_state_and_action(cld_handle h, const float* positions, const float* yaws, const float* curr_speed,
+                                  float* out6, int32_t B, int32_t scaled_output, void* stream);
+
 /* Measurement aid for bench.py (no reference counterpart): while enabled, every launch of the
  * dominant kernel instance -- the Conv1d(k=5) + GroupNorm + Mish block producing 256 channels at
  * L = 13 (conv_block_kernel<13,13,1,5,32,4,1,32,1>: 7 launches with 256 input channels and one with

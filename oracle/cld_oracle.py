@@ -293,6 +293,55 @@ def decode(wdec, z: Tensor, cond: Tensor, cs: Tensor, descaled_output: bool = Tr
 
 
 # --------------------------------------------------------------------------- #
+# f-4  VAE encoder: state -> state+action, LSTM encoder, reparametrisation
+# --------------------------------------------------------------------------- #
+def state_to_state_and_action(pos: Tensor, yaw: Tensor, speed: Tensor, dt: float = 0.1, scaled: bool = False) -> Tensor:
+    """src/tbsim/models/diffuser_helpers.py:685-749 as called at models/context_utils.py:64-70:
+    pos [B,T,2], yaw [B,T,1], speed [B] -> [B,T,6] = (x, y, v, yaw, acc, yaw-rate); positions and yaw are
+    pre-padded with zeros, speed with curr_speed; yaw differences wrap through a floored modulo."""
+    B = pos.shape[0]
+    p = torch.cat((torch.zeros(B, 1, 2, dtype=pos.dtype), pos), dim=1)
+    y = torch.cat((torch.zeros(B, 1, 1, dtype=pos.dtype), yaw), dim=1)
+    vel = ((p[:, 1:, 0:1] - p[:, :-1, 0:1]) / dt * torch.cos(y[:, 1:]) +
+           (p[:, 1:, 1:2] - p[:, :-1, 1:2]) / dt * torch.sin(y[:, 1:]))
+    vel = torch.cat((speed[:, None, None], vel), dim=1)
+    acc = (vel[:, 1:] - vel[:, :-1]) / dt
+    period = 2 * np.pi
+    d = (y[:, 1:] - y[:, :-1] + period / 2) % period - period / 2
+    d = torch.where(d > np.pi, d - 2 * np.pi, d)
+    out = torch.cat((p[:, 1:], vel[:, 1:], y[:, 1:], acc, d / dt), dim=-1)
+    if scaled:                                              # VaeModel.scale_traj, vae_model.py:152
+        out = (out - torch.tensor(NORM_MEAN, dtype=out.dtype)) / torch.tensor(NORM_STD, dtype=out.dtype)
+    return out
+
+
+def traj2z(w: Dict[str, Tensor], x6: Tensor, cond: Tensor, noise: Optional[Tensor]):
+    """models/vae/lstm_vae.py:87-99 (Encoder :6-26): 2-layer LSTM(6->64), h0 = cond2hidden(cond), c0 = 0,
+    mu / logvar = Linear(64->4)(outputs), z = mu + noise * exp(0.5 logvar)."""
+    B, T, _ = x6.shape
+    H = w["lstm_enc.lstm.weight_hh_l0"].shape[1]
+    h0 = F.linear(cond, w["lstm_enc.cond2hidden.weight"], w["lstm_enc.cond2hidden.bias"])
+    h = [h0.clone(), h0.clone()]
+    c = [torch.zeros(B, H, dtype=x6.dtype), torch.zeros(B, H, dtype=x6.dtype)]
+    outs = []
+    for t in range(T):
+        inp = x6[:, t]
+        for l in range(2):
+            g = (F.linear(inp, w[f"lstm_enc.lstm.weight_ih_l{l}"], w[f"lstm_enc.lstm.bias_ih_l{l}"])
+                 + F.linear(h[l], w[f"lstm_enc.lstm.weight_hh_l{l}"], w[f"lstm_enc.lstm.bias_hh_l{l}"]))
+            gi, gf, gg, go = g.chunk(4, dim=1)
+            c[l] = torch.sigmoid(gf) * c[l] + torch.sigmoid(gi) * torch.tanh(gg)
+            h[l] = torch.sigmoid(go) * torch.tanh(c[l])
+            inp = h[l]
+        outs.append(inp)
+    y = torch.stack(outs, dim=1)
+    mu = F.linear(y, w["mu.weight"], w["mu.bias"])
+    lv = F.linear(y, w["logvar.weight"], w["logvar.bias"])
+    z = mu if noise is None else mu + noise * torch.exp(0.5 * lv)
+    return z, mu, lv
+
+
+# --------------------------------------------------------------------------- #
 # helpers for tests / bench
 # --------------------------------------------------------------------------- #
 def to_torch(d: dict, dtype=torch.float32) -> Dict[str, Tensor]:

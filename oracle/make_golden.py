@@ -111,15 +111,44 @@ def section_cfg(ref):
          pred_traj=x, x1=x1)
 
 
+def section_encoder(ref):
+    """VAE encoder row: the reference's convert_state_to_state_and_action
+    (diffuser_helpers.py:685-749) and LSTMVAE.traj2z (lstm_vae.py:87-99) with its randn_like draw supplied."""
+    import tbsim.models.diffuser_helpers as dh
+    B = 8
+    fut = synth.make_future(B, IN_SEED)
+    pos, yaw, spd = T(fut["target_positions"]), T(fut["target_yaws"]), T(fut["curr_speed"])
+    with torch.no_grad():
+        x6 = dh.convert_state_to_state_and_action(torch.cat((pos, yaw), dim=2), spd, 0.1)
+    mean = torch.tensor(ref.algo.nusc_norm_info.diffuser[0], dtype=torch.float32)
+    std = torch.tensor(ref.algo.nusc_norm_info.diffuser[1], dtype=torch.float32)
+    x6s = (x6 - mean) / std                     # VaeModel.scale_traj restated (it raises on CPU, vae_model.py:149)
+    vae = ref.LSTMVAE(6, 64, 4, 2, device=torch.device("cpu")).eval()
+    sd = vae.state_dict()
+    for k, v in list(synth.make_encoder_weights(W_SEED).items()) + list(synth.make_decoder_weights(W_SEED).items()):
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = T(v)
+    vae.load_state_dict(sd)
+    cond = T(synth.make_inputs(B, IN_SEED)["cond_feat"])
+    nz = T(synth.normal(NOISE_SEED, "enc_noise", (B, 52, 4)))
+    with torch.no_grad(), feed_noise([nz]):
+        z, mu, lv = vae.traj2z(x6s, cond)
+    save("encode", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "noise_seed": NOISE_SEED,
+                    "future": "synth.make_future(B, in_seed)", "noise": "normal(noise_seed,'enc_noise')"},
+         state_action=x6, z=z, mu=mu, logvar=lv)
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
     ref = _refimport.load()
     algo = ref.algo
-    if len(sys.argv) > 1 and sys.argv[1] == "cfg":      # regenerate only the newer fixture(s)
-        section_cfg(ref)
+    if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
+        for name in sys.argv[1:]:
+            {"cfg": section_cfg, "encoder": section_encoder}[name](ref)
         return
     section_cfg(ref)
+    section_encoder(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

@@ -154,3 +154,29 @@ def test_decode_golden(golden, eng_jitter):
     st = eng_jitter.action_to_state(torch.from_numpy(g["dyn_actions"]), cs, False, False).cpu().numpy()
     assert np.abs(st[..., :4] - g["dyn_states"]).max() <= 1e-4
     assert np.array_equal(st[..., 4:], g["dyn_actions"])
+
+
+def test_encoder_row_golden(golden):
+    """VAE encoder: state -> state+action, LSTM encoder, mu/logvar heads, reparametrisation."""
+    from cld_amd.engine import Engine
+    from cld_amd.vae_model import VaeModel
+    meta, g = golden("encode")
+    B = meta["B"]
+    e = Engine(100, "cuda:0")
+    e.load_state_dict(synth.make_unet_weights(0))
+    e.load_state_dict(synth.make_encoder_weights(meta["w_seed"]))
+    e.finalize()
+    fut = {k: torch.from_numpy(v) for k, v in synth.make_future(B, meta["in_seed"]).items()}
+    vae = VaeModel(engine=e)
+    x6 = vae.get_state_and_action_from_data_batch(fut).cpu().numpy()
+    assert np.abs(x6 - g["state_action"]).max() <= 2e-4
+    x6s = vae.get_state_and_action_from_data_batch(fut, scaled=True)
+    assert torch.allclose(x6s.cpu(), vae.scale_traj(torch.from_numpy(g["state_action"])), atol=2e-4)
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    nz = torch.from_numpy(synth.normal(meta["noise_seed"], "enc_noise", (B, 52, 4)))
+    z, mu, lv = vae.lstmvae.traj2z(x6s, cond, noise=nz)
+    for got, k in ((z, "z"), (mu, "mu"), (lv, "logvar")):
+        assert np.abs(got.cpu().numpy() - g[k]).max() <= 2e-5, k
+    # decoder absent on this handle: the call reports it instead of crashing
+    with pytest.raises(Exception):
+        e.lstm_decode(z, cond)

@@ -137,3 +137,21 @@ def test_decoder_and_dynamics(golden):
     assert np.abs(st.numpy() - g["dyn_states"]).max() <= 1e-4
     # the hand-made rows really hit the bounds they were built for
     assert g["dyn_states"][0, :, 2].max() == 30.0 and g["dyn_states"][1, :, 2].min() == -10.0
+
+
+def test_encoder_row(golden):
+    meta, g = golden("encode")
+    B = meta["B"]
+    fut = synth.make_future(B, meta["in_seed"])
+    x6 = O.state_to_state_and_action(torch.from_numpy(fut["target_positions"]), torch.from_numpy(fut["target_yaws"]),
+                                     torch.from_numpy(fut["curr_speed"]))
+    assert np.abs(x6.numpy() - g["state_action"]).max() <= 2e-4        # accelerations are O(1e2) differences / dt^2
+    assert np.abs(g["state_action"][0, :, 5]).max() < 40               # the spinning agent's yaw rate stays wrapped
+    x6s = O.state_to_state_and_action(torch.from_numpy(fut["target_positions"]), torch.from_numpy(fut["target_yaws"]),
+                                      torch.from_numpy(fut["curr_speed"]), scaled=True)
+    w = O.to_torch(synth.make_encoder_weights(meta["w_seed"]))
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    nz = torch.from_numpy(synth.normal(meta["noise_seed"], "enc_noise", (B, 52, 4)))
+    z, mu, lv = O.traj2z(w, x6s, cond, nz)
+    for got, k in ((z, "z"), (mu, "mu"), (lv, "logvar")):
+        assert np.abs(got.numpy() - g[k]).max() <= 1e-5, k
