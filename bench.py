@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=100)
     ap.add_argument("--cfg-w", type=float, default=0.0,
                     help="classifier-free guidance weight (BASELINE configs[2]: --agents 64 --cfg-w 2.0); 0 = off")
+    ap.add_argument("--closed-loop", type=int, default=0, metavar="SIM_STEPS",
+                    help="BASELINE configs[4]-style step: SIM_STEPS x (sample -> decode -> kinematic update -> gather); "
+                         "e.g. --closed-loop 20 --denoise-steps 50 --scenes 64 --agents 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     args = ap.parse_args()
@@ -82,7 +85,19 @@ def main():
     cs[:, 2] = torch.rand(B, device=dev, generator=g) * 15.0
     gathered = torch.empty(world * B, 52, 6, device=dev) if distributed else None
 
+    world0 = torch.zeros(B, 3, device=dev)
+
     def one_step():
+        if args.closed_loop:      # rollout loop of env_utils.py:255-304 kept on the device (policy.closed_loop_rollout)
+            world, c = world0, cs
+            for _ in range(args.closed_loop):
+                x0, _, _ = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w,
+                                      want_x1=False, want_logp=False)
+                traj = eng.decode(x0, cond, c, descaled_output=True)
+                if distributed:
+                    gather_trajectories(traj, gathered)
+                world, c = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), 4)
+            return traj
         x0, x1, logp = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w)
         traj = eng.decode(x0, cond, cs, descaled_output=True)
         if distributed:
@@ -124,14 +139,15 @@ def main():
                     "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
                     "flop_per_launch": flop / launches}
 
-    total_units = world * B * n * args.steps
+    total_units = world * B * n * args.steps * max(1, args.closed_loop)
     value = total_units / dt
     out = {
         "metric": "denoising-step·agent/s", "value": round(value, 1), "unit": "step·agent/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]" if (args.scenes, args.agents, args.cfg_w) == (32, 32, 0.0) else "custom")
+        "config": {"workload": ("BASELINE configs[1]" if (args.scenes, args.agents, args.cfg_w, args.closed_loop) == (32, 32, 0.0, 0) else "custom")
+                               + (f" closed loop, {args.closed_loop} sim steps per bench step, each" if args.closed_loop else "")
                                + f": {args.scenes} scenes x {args.agents} agents per GPU, {n} denoising steps "
                                "(DDPM ancestral loop of the reference), latent seq 52 x 4, cond 256, "
                                + (f"CFG w={args.cfg_w} (2 U-Net passes per step)" if args.cfg_w else "CFG off") + "; "

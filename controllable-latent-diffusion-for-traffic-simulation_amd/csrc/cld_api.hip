@@ -821,4 +821,12 @@ int cld_state_to_state_and_action(cld_handle h, const float* positions, const fl
     return CLD_OK;
 }
 
+int cld_world_step(cld_handle h, const float* traj, const float* centroid, const float* yaw, int32_t k, float* world,
+                   float* next_curr_states, int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!traj || !centroid || !yaw || !world || B < 1 || k < 0 || k >= T) return fail(h, CLD_ERR_ARG, "cld_world_step: bad argument");
+    HIPCK(h, launch_world_step(traj, centroid, yaw, k, world, next_curr_states, B, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
 }  // extern "C"

@@ -129,4 +129,10 @@ hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* 
 hipError_t launch_state_to_state_action(const DynParams& d, const float* pos, const float* yaw, const float* speed,
                                         float* out6, int B, int scaled_output, hipStream_t s);
 
+// closed-loop world update (src/tbsim/envs/env_trajdata.py:452-468): state k of the planned trajectory, given in the
+// agent frame at planning time, placed in the world: xy' = p_k @ [[c, s], [-s, c]] + centroid, h' = yaw + yaw_k.
+// traj [B,52,6]; centroid [B,2]; yaw [B]; out world [B,3] = (x, y, h) and next curr_states [B,4] = (0, 0, v_k, 0).
+hipError_t launch_world_step(const float* traj, const float* centroid, const float* yaw, int k, float* world,
+                             float* next_cs, int B, hipStream_t s);
+
 }  // namespace cld

@@ -440,4 +440,24 @@ hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* 
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+__global__ void world_step_kernel(const float* __restrict__ traj, const float* __restrict__ centroid,
+                                  const float* __restrict__ yaw, int k, float* __restrict__ world,
+                                  float* __restrict__ next_cs, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* t = traj + ((size_t)b * 52 + k) * 6;
+    const float c = cosf(yaw[b]), s = sinf(yaw[b]);
+    world[b * 3 + 0] = t[0] * c - t[1] * s + centroid[b * 2 + 0];     // [px, py] @ [[c, s], [-s, c]]
+    world[b * 3 + 1] = t[0] * s + t[1] * c + centroid[b * 2 + 1];
+    world[b * 3 + 2] = yaw[b] + t[3];
+    if (next_cs) { next_cs[b * 4 + 0] = 0.f; next_cs[b * 4 + 1] = 0.f; next_cs[b * 4 + 2] = t[2]; next_cs[b * 4 + 3] = 0.f; }
+}
+hipError_t launch_world_step(const float* traj, const float* centroid, const float* yaw, int k, float* world,
+                             float* next_cs, int B, hipStream_t s) {
+    hipLaunchKernelGGL(world_step_kernel, dim3((B + 255) / 256), dim3(256), 0, s, traj, centroid, yaw, k, world, next_cs, B);
+    return hipGetLastError();
+}
+
 }  // namespace cld

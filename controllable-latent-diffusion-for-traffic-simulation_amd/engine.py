@@ -225,6 +225,18 @@ class Engine:
                         "cld_state_to_state_and_action")
         return out
 
+    def world_step(self, traj, centroid, yaw, k: int):
+        """env_trajdata.py:452-468 for plan step k -> (world [B,3] = (x, y, h), next curr_states [B,4])."""
+        traj = self._f32(traj)
+        B = traj.shape[0]
+        traj = self._f32(traj, (B, T, 6)); centroid = self._f32(centroid, (B, 2)); yaw = self._f32(yaw, (B,))
+        world = torch.empty(B, 3, dtype=torch.float32, device=self.device)
+        ncs = torch.empty(B, 4, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_world_step(self._h, _ptr(traj), _ptr(centroid), _ptr(yaw), int(k), _ptr(world),
+                                                _ptr(ncs), B, self._stream()), "cld_world_step")
+        return world, ncs
+
     # ------------------------------------------------------------------ measurement
     def profile_enable(self, on: bool = True):
         self._check(self.lib.cld_profile_enable(self._h, int(on)), "cld_profile_enable")

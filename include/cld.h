@@ -163,6 +163,14 @@ int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const fl
 int cld_state_to_state_and_action(cld_handle h, const float* positions, const float* yaws, const float* curr_speed,
                                   float* out6, int32_t B, int32_t scaled_output, void* stream);
 
+/* Closed-loop kinematic update of EnvUnifiedSimulation._step (src/tbsim/envs/env_trajdata.py:452-468) for plan step k
+ * (the last of the n_step_action executed steps): traj [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate) in the agent frame
+ * at planning time, centroid [B,2], yaw [B] (world pose at planning time) -> world [B,3] = (x, y, h) with
+ * xy = traj_xy[k] @ [[cos, sin], [-sin, cos]] + centroid, h = yaw + traj_yaw[k]; next_curr_states [B,4] (optional) =
+ * (0, 0, v_k, 0), the agent-centric current state the next planning call conditions on (batch_utils.py:46-65). */
+int cld_world_step(cld_handle h, const float* traj, const float* centroid, const float* yaw, int32_t k, float* world,
+                   float* next_curr_states, int32_t B, void* stream);
+
 /* Measurement aid for bench.py (no reference counterpart): while enabled, every launch of the
  * dominant kernel instance -- the Conv1d(k=5) + GroupNorm + Mish block producing 256 channels at
  * L = 13 (conv_block_kernel<13,13,1,5,32,4,1,32,1>: 7 launches with 256 input channels and one with

@@ -156,3 +156,42 @@ def test_reference_call_surface(eng):
     assert xn.shape == (B, 52, 4) and sigma.shape == (B, 1, 1)
     lp = dm.log_prob(x4[:, 0], xn, {"cond_feat": cond}, torch.full((B,), 9))
     assert lp.shape == (B,) and bool(torch.isfinite(lp).all())
+
+
+def test_get_action_and_closed_loop(eng, oracle_w):
+    """policy surface (algos.py:2024-2099 contract) + world update (env_trajdata.py:452-468)."""
+    from cld_amd.dm_model import DmModel
+    from cld_amd.policy import Action, CldPolicy, closed_loop_rollout
+    from cld_amd.vae_model import VaeModel
+    O, w, wd = oracle_w
+    dm, vae = DmModel(None, None, 100, engine=eng), VaeModel(engine=eng)
+    pol = CldPolicy(dm, vae, disable_control_on_stationary=True)
+    B = 6
+    inp = synth.make_inputs(B, 21)
+    inp["curr_states"][0, 2] = 0.1                                    # one stationary agent
+    cond, cs = torch.from_numpy(inp["cond_feat"]).cuda(), torch.from_numpy(inp["curr_states"]).cuda()
+    nz = synth.make_noise(B, 100, 77)
+    noise = {"x_T": torch.from_numpy(nz["x_T"]), "noise": torch.from_numpy(nz["noise"])}
+    act, info = pol.get_action({"cond_feat": cond, "curr_states": cs}, step_index=0, noise=noise)
+    assert isinstance(act, Action) and act.positions.shape == (B, 52, 2) and act.yaws.shape == (B, 52, 1)
+    assert info["action_samples"]["positions"].shape == (B, 1, 52, 2)
+    assert float(act.positions[0].abs().max()) == 0.0 and float(act.yaws[0].abs().max()) == 0.0     # stationary -> zeroed
+    # the composition equals sample -> decode of the engine (bit for bit) and the oracle's chain to chain tolerance
+    x0, _, _ = eng.sample(noise["x_T"], cond, noise=noise["noise"])
+    tr = eng.decode(x0, cond, cs, descaled_output=True)
+    assert torch.equal(act.positions[1:], tr[1:, :, :2]) and torch.equal(act.yaws[1:], tr[1:, :, 3:4])
+    # world update vs a NumPy restatement of env_trajdata.py:452-468
+    centroid = torch.from_numpy(synth.normal(3, "ctr", (B, 2)) * 50).cuda()
+    yaw = torch.from_numpy(synth.uniform(3, "yaw", (B,), -3.1, 3.1)).cuda()
+    k = 4
+    world, ncs = eng.world_step(tr, centroid, yaw, k)
+    trn, cn, yn = tr.cpu().numpy().astype(np.float64), centroid.cpu().numpy().astype(np.float64), yaw.cpu().numpy().astype(np.float64)
+    for b in range(B):
+        wfa = np.array([[np.cos(yn[b]), np.sin(yn[b])], [-np.sin(yn[b]), np.cos(yn[b])]])
+        exp_xy = trn[b, k, :2] @ wfa + cn[b]
+        assert np.abs(world[b, :2].cpu().numpy() - exp_xy).max() <= 1e-3 * max(1.0, np.abs(exp_xy).max())
+        assert abs(float(world[b, 2]) - (yn[b] + trn[b, k, 3])) <= 1e-5
+    assert torch.equal(ncs[:, 2], tr[:, k, 2]) and float(ncs[:, [0, 1, 3]].abs().max()) == 0.0
+    # 3 closed-loop sim steps stay finite and move the non-stationary agents
+    poses = closed_loop_rollout(CldPolicy(dm, vae), lambda s, wld, c: cond, centroid, yaw, cs, n_sim_steps=3)
+    assert poses.shape == (3, B, 3) and bool(torch.isfinite(poses).all())
