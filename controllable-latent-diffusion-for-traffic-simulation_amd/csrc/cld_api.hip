@@ -235,23 +235,19 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
     if (!pick_tiling(la, b_pad, &ga) || !pick_tiling(lb, b_pad, &gb)) return hipErrorInvalidValue;
     h->launch_counter += 2;
     if (ga.nwn == gb.nwn && conv_pair_supported(ga, gb)) return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
-    hipError_t e = launch_conv(ga, aa, b_pad, 0, s);
-    return e != hipSuccess ? e : launch_conv(gb, ab, b_pad, 0, s);
+    hipError_t e = launch_conv(ga, aa, b_pad, s);
+    return e != hipSuccess ? e : launch_conv(gb, ab, b_pad, s);
 }
 
 hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
                     const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
-    ConvArgs a{};
-    a.x1 = x1; a.x2 = x2; a.c1_real = l.c1_real; a.c1_pad = l.c1_pad; a.c2 = l.c2;
-    a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
-    if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
-    a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
+    ConvArgs a = make_args(h, l, x1, x2, y, res, cb, tb_row);
     a.stamps = (h->stamp_buf && h->launch_counter == h->stamp_layer) ? h->stamp_buf : nullptr;
     h->launch_counter++;
     ConvGeom g;
     if (!pick_tiling(l, b_pad, &g)) return hipErrorInvalidValue;
     const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && l.c_out == 256;   // the dominant layer shape
-    if (!timed) return launch_conv(g, a, b_pad, 0, s);
+    if (!timed) return launch_conv(g, a, b_pad, s);
     if (h->prof_used + 2 > h->prof_ev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t ev;
@@ -262,7 +258,7 @@ hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const flo
     }
     hipError_t e = hipEventRecord(h->prof_ev[h->prof_used], s);
     if (e != hipSuccess) return e;
-    e = launch_conv(g, a, b_pad, 0, s);
+    e = launch_conv(g, a, b_pad, s);
     if (e != hipSuccess) return e;
     e = hipEventRecord(h->prof_ev[h->prof_used + 1], s);
     h->prof_used += 2;

@@ -59,7 +59,7 @@ struct ConvGeom {
     int ostr;     // output row stride (2 for the transposed conv halves)
     int padc;     // 1: the input has fewer real channels than one K chunk (the 4-channel latent)
 };
-hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, int grid_z_index, hipStream_t s);
+hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s);
 bool conv_geom_supported(const ConvGeom& g);
 // two independent convolutions with the same grid shape in ONE launch (blockIdx.z picks the role)
 hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s);

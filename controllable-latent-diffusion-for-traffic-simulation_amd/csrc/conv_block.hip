@@ -25,8 +25,9 @@
 //                2-row zero halo between agents, so the 5 taps are 5 shifted
 //                ds_read_b128 of the same image and need no boundary tests.
 //   B operand  : weights pre-packed on the host in MFMA fragment order; each
-//                lane fetches its fragment with ONE coalesced global_load_dwordx4
-//                per (tap, 16-channel group) -- weights never touch LDS.
+//                lane fetches its fragment with ONE coalesced buffer_load_dwordx4 (scalar
+//                offset, loop-invariant per-lane offset) per (tap, 16-channel group) --
+//                weights never touch LDS.
 //   k order    : lane (i, kk) holds channels 4kk..4kk+3 of a 16-channel group and
 //                feeds them to 4 successive MFMAs; A and B use the same
 //                permutation, so the sum over k is unchanged.
@@ -79,7 +80,6 @@ template <> __device__ __forceinline__ float vget<1>(const float& v, int) { retu
 template <int W> __device__ __forceinline__ void vset(typename VecT<W>::type& v, int e, float x) { v[e] = x; }
 template <> __device__ __forceinline__ void vset<1>(float& v, int, float x) { v = x; }
 
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     // buffer_load_dwordx4 v, voff, rsrc, soff offen: the per-lane part of the address is a loop-invariant VGPR
     // and everything that changes per chunk / iteration is a scalar -- no vector ALU work per load.
@@ -547,7 +547,7 @@ bool conv_geom_supported(const ConvGeom& g) {
     return false;
 }
 
-hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, int /*grid_z_index*/, hipStream_t s) {
+hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
 #define X(a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_) \
     if (geom_is(g, a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_)) return launch_inst<a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_>(a, b_pad, s);
     CLD_CONV_INSTANCES(X)

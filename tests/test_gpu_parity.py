@@ -124,6 +124,23 @@ def test_cfg_chain_golden(golden):
     assert torch.equal(a, b)
 
 
+def test_cfg_ragged_batch_vs_oracle():
+    """CFG with a batch that is not a multiple of the 16-agent tile: the two halves of the 2B launch set stay
+    tile-aligned (rows [0,32) cond, [32,64) uncond for B = 20)."""
+    from oracle import cld_oracle as O
+    B, n, wgt = 20, 10, 1.5
+    e = _engine(n, True, decoder=False)
+    w = O.to_torch(synth.make_unet_weights(0, affine_jitter=True))
+    cond = torch.from_numpy(synth.make_inputs(B, 31)["cond_feat"])
+    non_cond = torch.from_numpy(synth.normal(31, "nc", (B, 256)))
+    nz = synth.make_noise(B, n, 32)
+    ref = O.sample_cfg(w, O.schedule(n), torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"]), cond, non_cond, wgt)
+    x0, x1, _ = e.sample(torch.from_numpy(nz["x_T"]), cond, noise=torch.from_numpy(nz["noise"]), non_cond=non_cond, guidance_w=wgt)
+    scale = float(ref["pred_traj"].abs().max())
+    assert float((x0.cpu() - ref["pred_traj"]).abs().max()) <= 1e-3 * scale
+    assert float((x1.cpu() - ref["x1"]).abs().max()) <= 1e-3 * scale
+
+
 def test_log_prob_golden(golden, eng_jitter):
     meta, g = golden("log_prob")
     B = meta["B"]
