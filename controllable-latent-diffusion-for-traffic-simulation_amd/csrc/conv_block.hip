@@ -279,21 +279,26 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     }
     STAMP(2);
 
-    // ---- epilogue mapping: TPP lanes per (agent, group), 13 vectors of VW channels each --------
-    constexpr int VW = (16 * NT) / NTHR;
+    // ---- epilogue mapping: TPP lanes per (agent, group); every lane handles float4 channel vectors of NV rows
+    //      (16-byte LDS reads, residual loads and stores in both tilings; the last row slot is empty for some
+    //      lanes when the rows of an agent do not divide evenly) ----
+    constexpr int VW = 4;
     constexpr int NG = NT / GS;
     constexpr int PAIRS = AG * NG;
     constexpr int TPP = NTHR / PAIRS;
-    constexpr int VPR = GS / VW;
-    constexpr int RPI = TPP / VPR;
-    static_assert(VW >= 1 && PAIRS * TPP == NTHR && VPR * RPI == TPP && RPI * 13 == LM, "epilogue mapping");
+    constexpr int VPR = GS / VW;                     // vectors per row of a group
+    constexpr int RPI = TPP / VPR;                   // rows covered per iteration by the lanes of a pair
+    constexpr int NV = (LM + RPI - 1) / RPI;         // row slots per lane: 13 (tiling A) or 7 (tiling B)
+    constexpr bool RAGGED = NV * RPI != LM;
+    static_assert(PAIRS * TPP == NTHR && VPR * RPI == TPP && VPR >= 1, "epilogue mapping");
     typedef typename VecT<VW>::type vec_t;
 
     const int pair = tid / TPP, q = tid % TPP;
     const int a = pair / NG, g = pair % NG;
     const int ch = g * GS + (q % VPR) * VW;          // channel within the tile
-    const int n = by * NT + ch;              // global output channel
+    const int n = by * NT + ch;                      // global output channel
     const int jr = q / VPR;
+    const bool last_ok = !RAGGED || (RPI * (NV - 1) + jr < LM);      // does this lane own a row in the last slot?
     const size_t obase = ((size_t)(b0 + a) * p.ly + (OSTR * jr + p.orow0)) * p.c_out + n;
     const size_t ostep = (size_t)OSTR * RPI * p.c_out;
 
@@ -306,10 +311,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         if (p.cbias) cbv = *reinterpret_cast<const vec_t*>(p.cbias + (size_t)(b0 + a) * p.cb_stride + n);
         if (p.tbias) tbv = *reinterpret_cast<const vec_t*>(p.tbias + n);
     }
-    vec_t rv[13];
+    vec_t rv[NV];
     if (p.res) {
 #pragma unroll
-        for (int i = 0; i < 13; ++i) rv[i] = *reinterpret_cast<const vec_t*>(p.res + obase + i * ostep);
+        for (int i = 0; i < NV; ++i)
+            rv[i] = (i < NV - 1 || last_ok) ? *reinterpret_cast<const vec_t*>(p.res + obase + i * ostep) : vec_t{0.f, 0.f, 0.f, 0.f};
     }
 
     __syncthreads();               // every wave is done reading the images before the output tile overwrites them
@@ -332,10 +338,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     __syncthreads();
     STAMP(4);
 
-    float v[13][VW];
+    float v[NV][VW];
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
-        const int j = RPI * i + jr;
+    for (int i = 0; i < NV; ++i) {
+        const int j = (i < NV - 1 || last_ok) ? RPI * i + jr : jr;      // an empty slot re-reads row jr and is masked below
         const vec_t o = *reinterpret_cast<const vec_t*>(O + (a * LM + j) * OP + ch);
 #pragma unroll
         for (int e = 0; e < VW; ++e) v[i][e] = vget<VW>(o, e) + vget<VW>(bias, e);
@@ -352,17 +358,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         // (torch.nn.GroupNorm as used in diffuser_helpers.py:61).
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int e = 0; e < VW; ++e) s += v[i][e];
+            for (int e = 0; e < VW; ++e) s += (i < NV - 1 || last_ok) ? v[i][e] : 0.f;
 #pragma unroll
         for (int o = 1; o < TPP; o <<= 1) s += __shfl_xor(s, o);
         const float mean = s * (1.0f / (float)(GS * LM));
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int e = 0; e < VW; ++e) { const float d = v[i][e] - mean; ss += d * d; }
+            for (int e = 0; e < VW; ++e) { const float d = v[i][e] - mean; ss += (i < NV - 1 || last_ok) ? d * d : 0.f; }
 #pragma unroll
         for (int o = 1; o < TPP; o <<= 1) ss += __shfl_xor(ss, o);
         const float rstd = 1.0f / sqrtf(ss * (1.0f / (float)(GS * LM)) + 1e-5f);
@@ -374,18 +380,18 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
             sh[e] = vget<VW>(bet, e);
         }
 #pragma unroll
-        for (int i = 0; i < 13; ++i)
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int e = 0; e < VW; ++e) v[i][e] = mish_f((v[i][e] - mean) * sc[e] + sh[e]) + add[e];
     }
 
     STAMP(5);
 #pragma unroll
-    for (int i = 0; i < 13; ++i) {
+    for (int i = 0; i < NV; ++i) {
         vec_t o;
 #pragma unroll
         for (int e = 0; e < VW; ++e) vset<VW>(o, e, p.res ? v[i][e] + vget<VW>(rv[i], e) : v[i][e]);
-        *reinterpret_cast<vec_t*>(p.y + obase + i * ostep) = o;
+        if (i < NV - 1 || last_ok) *reinterpret_cast<vec_t*>(p.y + obase + i * ostep) = o;
     }
     STAMP(6);
     STAMP_RT(9);
