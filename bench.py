@@ -133,8 +133,8 @@ def main():
             ach = flop / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
-                    "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0> (Conv1d k5 -> 256 ch + GroupNorm + Mish at L=13; "
-                               "7 launches/step with 256 input channels, 1 with 128; tiling picked by batch size)"
+                    "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0> (Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; "
+                               "7 launches per U-Net evaluation; tiling picked by batch size)"
                                % ("4,1" if (B + 15) // 16 * 4 * 4 >= 2048 else "2,2")),
                     "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
                     "flop_per_launch": flop / launches}
