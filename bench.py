@@ -58,9 +58,18 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        # "nccl" is RCCL on ROCm.  CLD_DIST_BACKEND=gloo only exists to rehearse the multi-process flow on a box
+        # with fewer GPUs than ranks (ranks then share devices; the gather stages through the host).
+        backend = os.environ.get("CLD_DIST_BACKEND", "nccl")
+        local_dev = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group(backend=backend)
+    else:
+        local_dev = local_rank % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local_dev)
     torch.cuda.set_device(dev)
 
     from cld_amd import synth

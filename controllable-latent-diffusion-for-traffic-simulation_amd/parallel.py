@@ -41,6 +41,11 @@ def gather_trajectories(local: torch.Tensor, out: torch.Tensor = None, group=Non
     local = local.contiguous()
     if out is None:
         out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal backend: stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, local.cpu(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, local, group=group)
     return out
 
