@@ -435,7 +435,7 @@ int cld_finalize(cld_handle h, void* stream) {
     // ---- conv layers -------------------------------------------------------------------
     auto make_conv = [&](ConvLayer& l, const std::string& wname, int c_out, int c1_real, int c2, int L_in, int lm,
                          int stride, int ntaps, const int* tapk, bool transposed, int off0, int orow0, int ostr,
-                         int ly, int epi, const std::string& gn_name, int nwn) -> int {
+                         int ly, int epi, const std::string& gn_name) -> int {
         const std::vector<float>& W = *getw(h, wname + ".weight");
         const int c1_pad = (c1_real + 31) / 32 * 32;     // the 4-channel latent is padded to one 32-channel chunk
         const int cin_real = c1_real + c2;
@@ -456,7 +456,6 @@ int cld_finalize(cld_handle h, void* stream) {
             UP(l.beta, *getw(h, gn_name + ".bias"));
         }
         l.c_out = c_out; l.c1_real = c1_real; l.c1_pad = c1_pad; l.c2 = c2; l.ly = ly; l.off0 = off0; l.orow0 = orow0;
-        (void)nwn;
         l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0};
         if (c2 > 0 && c2 != c1_real) return fail(h, CLD_ERR_ARG, "cld_finalize: concatenated sources must have equal channel counts");
         ConvGeom t = l.g;
@@ -476,30 +475,27 @@ int cld_finalize(cld_handle h, void* stream) {
         const std::string p = bd.name;
         const bool cat = (i == 8 || i == 10);
         const int c1 = cat ? bd.cin / 2 : bd.cin, c2 = cat ? bd.cin / 2 : 0;
-        // N tiling: 64 output channels per workgroup, except where that would leave fewer N-tiles than the
-        // other layers of the level (the up path): 32 + a 2-way K split keeps all four waves busy.
-        const int nwn = (i >= 8) ? 2 : 4;
         if ((rc = make_conv(rb.c0, p + ".blocks.0.block.0", bd.cout, c1, c2, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1, bd.L,
-                            EPI_GN_MISH, p + ".blocks.0.block.2", nwn)) != CLD_OK) return rc;
+                            EPI_GN_MISH, p + ".blocks.0.block.2")) != CLD_OK) return rc;
         rb.c0.cb_off = cb_off;
         if ((rc = make_conv(rb.c1, p + ".blocks.1.block.0", bd.cout, bd.cout, 0, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1,
-                            bd.L, EPI_GN_MISH, p + ".blocks.1.block.2", nwn)) != CLD_OK) return rc;
+                            bd.L, EPI_GN_MISH, p + ".blocks.1.block.2")) != CLD_OK) return rc;
         rb.has_res = bd.cin != bd.cout;
         if (rb.has_res)
             if ((rc = make_conv(rb.res, p + ".residual_conv", bd.cout, c1, c2, bd.L, bd.L, 1, 1, k1, false, 0, 0, 1, bd.L,
-                                EPI_BIAS, "", nwn)) != CLD_OK) return rc;
+                                EPI_BIAS, "")) != CLD_OK) return rc;
         cb_off += bd.cout;
     }
-    if ((rc = make_conv(h->down[0], "model.downs.0.2.conv", 64, 64, 0, 52, 26, 2, 3, k3, false, -1, 0, 1, 26, EPI_BIAS, "", 2))) return rc;
-    if ((rc = make_conv(h->down[1], "model.downs.1.2.conv", 128, 128, 0, 26, 13, 2, 3, k3, false, -1, 0, 1, 13, EPI_BIAS, "", 2))) return rc;
+    if ((rc = make_conv(h->down[0], "model.downs.0.2.conv", 64, 64, 0, 52, 26, 2, 3, k3, false, -1, 0, 1, 26, EPI_BIAS, ""))) return rc;
+    if ((rc = make_conv(h->down[1], "model.downs.1.2.conv", 128, 128, 0, 26, 13, 2, 3, k3, false, -1, 0, 1, 13, EPI_BIAS, ""))) return rc;
     for (int u = 0; u < 2; ++u) {
         const std::string p = u == 0 ? "model.ups.0.2.conv" : "model.ups.1.2.conv";
         const int c = u == 0 ? 128 : 64, L = u == 0 ? 13 : 26;
-        if ((rc = make_conv(h->upT[u][0], p, c, c, 0, L, L, 1, 2, kT_even, true, -1, 0, 2, 2 * L, EPI_BIAS, "", 4))) return rc;
-        if ((rc = make_conv(h->upT[u][1], p, c, c, 0, L, L, 1, 2, kT_odd, true, 0, 1, 2, 2 * L, EPI_BIAS, "", 4))) return rc;
+        if ((rc = make_conv(h->upT[u][0], p, c, c, 0, L, L, 1, 2, kT_even, true, -1, 0, 2, 2 * L, EPI_BIAS, ""))) return rc;
+        if ((rc = make_conv(h->upT[u][1], p, c, c, 0, L, L, 1, 2, kT_odd, true, 0, 1, 2, 2 * L, EPI_BIAS, ""))) return rc;
     }
     if ((rc = make_conv(h->final_cb, "model.final_conv.0.block.0", 64, 64, 0, 52, 52, 1, 5, k5, false, -2, 0, 1, 52,
-                        EPI_GN_MISH, "model.final_conv.0.block.2", 4))) return rc;
+                        EPI_GN_MISH, "model.final_conv.0.block.2"))) return rc;
 
     // ---- cond half of every block's time_mlp Linear, concatenated: wc [1792][256], bias [1792] ----
     // ---- time half folded with the timestep embedding into a table tb [n_timesteps][1792]       ----
