@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--closed-loop", type=int, default=0, metavar="SIM_STEPS",
                     help="BASELINE configs[4]-style step: SIM_STEPS x (sample -> decode -> kinematic update -> gather); "
                          "e.g. --closed-loop 20 --denoise-steps 50 --scenes 64 --agents 64")
+    ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
+                    help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split operands with fp32 accumulation (include/cld.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     args = ap.parse_args()
@@ -78,7 +80,7 @@ def main():
 
     n = args.denoise_steps
     B = args.scenes * args.agents
-    eng = Engine(n_timesteps=n, device=dev)
+    eng = Engine(n_timesteps=n, device=dev, precision=args.precision)
     eng.load_state_dict(synth.make_unet_weights(0))            # PyTorch-default-like random init (no checkpoint ships)
     eng.load_state_dict(synth.make_decoder_weights(0))
     eng.finalize()

@@ -24,7 +24,11 @@ class CldConfig(C.Structure):
         ("step_time", C.c_float), ("acce_bound", C.c_float * 2), ("v_bound", C.c_float * 2),
         ("max_steer", C.c_float), ("max_yawvel", C.c_float),
         ("norm_mean", C.c_float * 6), ("norm_std", C.c_float * 6),
+        ("precision", C.c_int32),
     ]
+
+
+PRECISIONS = {"f32": 0, "f16x2": 1}
 
 
 _P = C.c_void_p
@@ -52,6 +56,7 @@ SIGNATURES = {
     "cld_profile_enable": (C.c_int, [_P, C.c_int32]),
     "cld_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cld_debug_stamps": (C.c_int, [_P, _P, C.c_int32]),
+    "cld_get_precision": (C.c_int, [_P]),
     "cld_version": (C.c_char_p, []),
 }
 

@@ -45,6 +45,7 @@ struct ResBlock { ConvLayer c0, c1, res; bool has_res = false; };
 
 struct cld_handle_s {
     cld_config cfg{};
+    int precision = CLD_PRECISION_F32;               // cfg.precision, possibly overridden by CLD_PRECISION (experiments)
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
     std::map<std::string, size_t> expect;            // name -> numel
@@ -183,6 +184,32 @@ std::vector<float> pack_conv_weights(F&& wget, int c_out, int cin_virtual, int n
     return out;
 }
 
+// Split-precision packing (CLD_PRECISION_F16X2).  Weights are scaled by kWScale (a power of two that lifts the lo parts
+// out of the fp16 subnormal range; undone exactly in the epilogue) and split into hi = fp16(w), lo = fp16(w - hi).
+// Slab (32-channel chunk c, tap t, N tile nt) = [hi: 64 lanes x 8 fp16][lo: 64 lanes x 8 fp16]; lane l holds
+// W[co = 16 nt + (l & 15)][ci = 32 c + 8 (l >> 4) + j][tap t], j = 0..7 -- the B operand of v_mfma_f32_16x16x32_f16.
+constexpr float kWScale = 64.0f;
+template <class F>
+std::vector<float> pack_conv_weights_split(F&& wget, int c_out, int cin_virtual, int ntaps) {
+    const int nchunk = cin_virtual / 32, ntn = c_out / 16;
+    std::vector<_Float16> out((size_t)nchunk * ntaps * ntn * 1024);
+    size_t o = 0;
+    for (int c = 0; c < nchunk; ++c)
+        for (int t = 0; t < ntaps; ++t)
+            for (int nt = 0; nt < ntn; ++nt) {
+                for (int plane = 0; plane < 2; ++plane)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const float w = wget(16 * nt + (lane & 15), 32 * c + 8 * (lane >> 4) + j, t) * kWScale;
+                            const _Float16 hi = (_Float16)w;
+                            out[o++] = plane == 0 ? hi : (_Float16)(w - (float)hi);
+                        }
+            }
+    std::vector<float> bytes(out.size() / 2);
+    std::memcpy(bytes.data(), out.data(), out.size() * sizeof(_Float16));
+    return bytes;
+}
+
 // Tiling policy: the MFMA/LDS/global-load mix of the conv loop reaches ~83 % of the fp32-MFMA rate with one
 // wave per SIMD and ~89 % with two (scripts/ubench/mfma_issue.hip), so take the 64-column tile when it still
 // puts two waves on every SIMD of the chip (256 CUs x 4 SIMDs x 2 = 2,048 waves) and the 32-column tile with a
@@ -192,6 +219,7 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     *g = l.g;
     const long waves_a = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64) * 4;
     auto set = [&](int kc, int nwn, int ks) { g->kc = kc; g->nwn = nwn; g->ks = ks; return true; };
+    if (l.g.ain == 1) return l.has_a ? set(32, 4, 1) : false;  // split-precision loop: 64-column tiling only (no K split)
     static const char* force = getenv("CLD_TILING");            // experiments only: A / B
     if (force && force[0] == 'A' && l.has_a) return set(32, 4, 1);
     if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
@@ -223,6 +251,7 @@ ConvArgs make_args(cld_handle h, const ConvLayer& l, const float* x1, const floa
     a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
     if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
     a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
+    a.wscale_inv = l.g.ain == 1 ? 1.0f / kWScale : 1.0f;
     a.stamps = nullptr;
     (void)h;
     return a;
@@ -233,6 +262,8 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
                     int b_pad, hipStream_t s) {
     ConvGeom ga, gb;
     if (!pick_tiling(la, b_pad, &ga) || !pick_tiling(lb, b_pad, &gb)) return hipErrorInvalidValue;
+    static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;   // diagnostics
+    if (h->launch_counter >= stop_after) return hipSuccess;
     h->launch_counter += 2;
     if (ga.nwn == gb.nwn && conv_pair_supported(ga, gb)) return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
     hipError_t e = launch_conv(ga, aa, b_pad, s);
@@ -242,6 +273,8 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
 hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
                     const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
     ConvArgs a = make_args(h, l, x1, x2, y, res, cb, tb_row);
+    static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;   // diagnostics
+    if (h->launch_counter >= stop_after) return hipSuccess;
     a.stamps = (h->stamp_buf && h->launch_counter == h->stamp_layer) ? h->stamp_buf : nullptr;
     h->launch_counter++;
     ConvGeom g;
@@ -324,7 +357,9 @@ const std::vector<float>* getw(cld_handle h, const std::string& k) {
 // =============================================================================================
 extern "C" {
 
-const char* cld_version(void) { return "libcld_hip 0.1.0 gfx950 mfma_f32_16x16x4"; }
+const char* cld_version(void) { return "libcld_hip 0.1.0 gfx950 mfma_f32_16x16x4 / f16x2-split mfma_f32_16x16x32_f16"; }
+
+int cld_get_precision(cld_handle h) { return h ? h->precision : CLD_ERR_ARG; }
 
 void cld_default_config(cld_config* c) {
     if (!c) return;
@@ -337,6 +372,7 @@ void cld_default_config(cld_config* c) {
     const float mean[6] = {13.162f, -0.13891f, 5.0223f, -0.0046415f, -0.0080072f, -0.0013546f};
     const float stdv[6] = {13.0717f, 2.2462f, 3.6187f, 0.2210f, 2.5770f, 0.0840f};
     for (int i = 0; i < 6; ++i) { c->norm_mean[i] = mean[i]; c->norm_std[i] = stdv[i]; }
+    c->precision = CLD_PRECISION_F32;
 }
 
 int cld_create(const cld_config* cfg, cld_handle* out) {
@@ -350,6 +386,9 @@ int cld_create(const cld_config* cfg, cld_handle* out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return CLD_ERR_HIP;
     cld_handle h = new cld_handle_s();
     h->cfg = *cfg;
+    h->precision = cfg->precision;
+    if (const char* v = getenv("CLD_PRECISION")) h->precision = (v[0] == 'f' && v[1] == '1') ? CLD_PRECISION_F16X2 : CLD_PRECISION_F32;
+    if (h->precision != CLD_PRECISION_F32 && h->precision != CLD_PRECISION_F16X2) { delete h; return CLD_ERR_ARG; }
     add_expect(h);
     build_schedule(h);
     DynParams& d = h->dyn;
@@ -435,7 +474,9 @@ int cld_finalize(cld_handle h, void* stream) {
     // ---- conv layers -------------------------------------------------------------------
     auto make_conv = [&](ConvLayer& l, const std::string& wname, int c_out, int c1_real, int c2, int L_in, int lm,
                          int stride, int ntaps, const int* tapk, bool transposed, int off0, int orow0, int ostr,
-                         int ly, int epi, const std::string& gn_name) -> int {
+                         int ly, int epi, const std::string& gn_name, bool in_f32 = false, bool out_f32 = false) -> int {
+        const bool split = h->precision == CLD_PRECISION_F16X2;
+        const int ain = (split && !in_f32) ? 1 : 0, aout = (split && !out_f32) ? 1 : 0;
         const std::vector<float>& W = *getw(h, wname + ".weight");
         const int c1_pad = (c1_real + 31) / 32 * 32;     // the 4-channel latent is padded to one 32-channel chunk
         const int cin_real = c1_real + c2;
@@ -448,7 +489,8 @@ int cld_finalize(cld_handle h, void* stream) {
             return transposed ? W[((size_t)ci * c_out + co) * kw + k]     // ConvTranspose1d [C_in, C_out, k]
                               : W[((size_t)co * cin_real + ci) * kw + k]; // Conv1d [C_out, C_in, k]
         };
-        std::vector<float> packed = pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
+        std::vector<float> packed = ain ? pack_conv_weights_split(wget, c_out, c1_pad + c2, ntaps)
+                                        : pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
         UP(l.wfrag, packed);
         UP(l.bias, *getw(h, wname + ".bias"));
         if (epi == EPI_GN_MISH) {
@@ -456,7 +498,7 @@ int cld_finalize(cld_handle h, void* stream) {
             UP(l.beta, *getw(h, gn_name + ".bias"));
         }
         l.c_out = c_out; l.c1_real = c1_real; l.c1_pad = c1_pad; l.c2 = c2; l.ly = ly; l.off0 = off0; l.orow0 = orow0;
-        l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0};
+        l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0, ain, aout};
         if (c2 > 0 && c2 != c1_real) return fail(h, CLD_ERR_ARG, "cld_finalize: concatenated sources must have equal channel counts");
         ConvGeom t = l.g;
         l.has_a = conv_geom_supported(t);
@@ -475,15 +517,16 @@ int cld_finalize(cld_handle h, void* stream) {
         const std::string p = bd.name;
         const bool cat = (i == 8 || i == 10);
         const int c1 = cat ? bd.cin / 2 : bd.cin, c2 = cat ? bd.cin / 2 : 0;
+        const bool latent_in = (i == 0);     // the 4-channel latent stays fp32 (its range is unbounded): exact-fp32 loop
         if ((rc = make_conv(rb.c0, p + ".blocks.0.block.0", bd.cout, c1, c2, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1, bd.L,
-                            EPI_GN_MISH, p + ".blocks.0.block.2")) != CLD_OK) return rc;
+                            EPI_GN_MISH, p + ".blocks.0.block.2", latent_in)) != CLD_OK) return rc;
         rb.c0.cb_off = cb_off;
         if ((rc = make_conv(rb.c1, p + ".blocks.1.block.0", bd.cout, bd.cout, 0, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1,
                             bd.L, EPI_GN_MISH, p + ".blocks.1.block.2")) != CLD_OK) return rc;
         rb.has_res = bd.cin != bd.cout;
         if (rb.has_res)
             if ((rc = make_conv(rb.res, p + ".residual_conv", bd.cout, c1, c2, bd.L, bd.L, 1, 1, k1, false, 0, 0, 1, bd.L,
-                                EPI_BIAS, "")) != CLD_OK) return rc;
+                                EPI_BIAS, "", latent_in)) != CLD_OK) return rc;
         cb_off += bd.cout;
     }
     if ((rc = make_conv(h->down[0], "model.downs.0.2.conv", 64, 64, 0, 52, 26, 2, 3, k3, false, -1, 0, 1, 26, EPI_BIAS, ""))) return rc;
@@ -495,7 +538,7 @@ int cld_finalize(cld_handle h, void* stream) {
         if ((rc = make_conv(h->upT[u][1], p, c, c, 0, L, L, 1, 2, kT_odd, true, 0, 1, 2, 2 * L, EPI_BIAS, ""))) return rc;
     }
     if ((rc = make_conv(h->final_cb, "model.final_conv.0.block.0", 64, 64, 0, 52, 52, 1, 5, k5, false, -2, 0, 1, 52,
-                        EPI_GN_MISH, "model.final_conv.0.block.2"))) return rc;
+                        EPI_GN_MISH, "model.final_conv.0.block.2", false, /*out_f32: the head kernel reads fp32*/ true))) return rc;
 
     // ---- cond half of every block's time_mlp Linear, concatenated: wc [1792][256], bias [1792] ----
     // ---- time half folded with the timestep embedding into a table tb [n_timesteps][1792]       ----

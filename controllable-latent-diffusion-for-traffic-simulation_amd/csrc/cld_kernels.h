@@ -42,6 +42,7 @@ struct ConvArgs {
     int ly;               // rows per agent of the OUTPUT tensor
     int off0;             // input row of tap 0 relative to STRIDE*j
     int orow0;            // output row = OSTR*j + orow0
+    float wscale_inv;     // split-precision mode: 1 / (power-of-two scale applied to the weights before splitting)
     unsigned long long* stamps;   // diagnostic builds (-DCLD_STAMPS) only: 16 u64 per workgroup; null otherwise
 };
 
@@ -58,6 +59,8 @@ struct ConvGeom {
     int gs;       // GroupNorm group size (channels) = c_out / 8
     int ostr;     // output row stride (2 for the transposed conv halves)
     int padc;     // 1: the input has fewer real channels than one K chunk (the 4-channel latent)
+    int ain;      // activation format of the input: 0 = fp32, 1 = S22 (fp16 hi/lo planes, split-precision loop)
+    int aout;     // activation format of the output and of the residual
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s);
 bool conv_geom_supported(const ConvGeom& g);

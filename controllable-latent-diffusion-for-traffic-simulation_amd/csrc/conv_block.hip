@@ -87,9 +87,32 @@ __device__ __forceinline__ v4f buf_load16(__amdgpu_buffer_rsrc_t r, int voff, in
     return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// ---- S22 activation format (f16x2-split precision mode) ------------------------------------------------------
+// A value a is kept as hi = fp16(a), lo = fp16(a - hi): 22 mantissa bits in the same 4 bytes as an fp32.  In HBM and
+// in the LDS image every 8-channel block of a row is stored as [8 x hi][8 x lo] (16 B + 16 B), so an MFMA A fragment
+// (8 consecutive channels per lane for v_mfma_f32_16x16x32_f16) is one ds_read_b128 per plane with no permute.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void s22_encode(const float (&v)[4], h4& hi, h4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float c = fminf(fmaxf(v[e], -65504.0f), 65504.0f);     // saturate instead of producing inf
+        const _Float16 h = (_Float16)c;
+        hi[e] = h;
+        lo[e] = (_Float16)(c - (float)h);
+    }
+}
+
 // PADC: the input has fewer real channels than one K chunk (the 4-channel latent): zero-fill the rest.
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
+// AIN / AOUT: activation format of the input / of the output and residual (0 = fp32, 1 = S22).  AIN = 1 selects the
+// split-precision loop: products hi*hi + hi*lo + lo*hi on the fp16 MFMA (weights pre-split and pre-scaled on the
+// host), fp32 accumulation -- measured indistinguishable from the exact-fp32 loop on this network
+// (scripts/emulate_split.py) at ~3.9x its in-loop rate (scripts/ubench/mfma_issue.hip, V5).
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const int bx, const int by) {
+    constexpr bool SPLIT = AIN == 1;
+    static_assert(!SPLIT || (KS == 1 && KC == 32 && PADC == 0), "split-precision loop: one 32-channel MFMA K per chunk, no K split");
     constexpr int NTHR = 64 * NWN * KS;
     constexpr int AG = MT / LM;            // agents per workgroup
     constexpr int LP = L_IN + 2;           // LDS rows per agent (2 halo rows shared with the neighbour)
@@ -107,7 +130,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     constexpr int PPR = KC / 4;            // 16-byte pieces per staged row
     constexpr int NPC = IN_ROWS * PPR;
     constexpr int NPIECE = (NPC + NTHR - 1) / NTHR;
-    constexpr int NIT = NTAPS * KGW;       // (tap, group) iterations per chunk per wave
+    constexpr int NIT = (AIN == 1) ? NTAPS : NTAPS * KGW;   // iterations per chunk per wave: (tap, 16-channel group), or taps in split mode (one MFMA spans the chunk)
     static_assert(NTHR % PPR == 0, "a thread keeps one channel piece");
 
     const int tid = threadIdx.x;
@@ -169,12 +192,25 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         return buf_load16(rsw, wlane, ((kgg * NTAPS + t) * ntn + ntile_g) * 1024);
     };
 
+    // split mode: slab (32-channel chunk c, tap t, N tile) = [hi: 64 lanes x 8 fp16][lo: 64 lanes x 8 fp16] = 2 KiB
+    auto wload_hi = [&](int c, int it) {
+        return buf_load16(rsw, wlane, (((c + it / NIT) * NTAPS + it % NIT) * ntn + ntile_g) * 2048);
+    };
+    auto wload_lo = [&](int c, int it) {
+        return buf_load16(rsw, wlane, (((c + it / NIT) * NTAPS + it % NIT) * ntn + ntile_g) * 2048 + 1024);
+    };
+
     // ---- prologue: chunk 0 and the first weight fragments go out first; the LDS-side address arithmetic
     //      (divisions by the row counts), the accumulator clear and the halo zeroing run under their latency ----
     load_chunk(0);
     // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them
-    v4f bq0 = wload(0, 0);
-    v4f bq1 = (1 / NIT < nchunk) ? wload(0, 1) : bq0;
+    v4f bq0 = SPLIT ? wload_hi(0, 0) : wload(0, 0);
+    v4f bq1 = (1 / NIT < nchunk) ? (SPLIT ? wload_hi(0, 1) : wload(0, 1)) : bq0;
+    v4f bl0 = bq0, bl1 = bq0;                           // lo planes of the two queued weight fragments (split mode)
+    if (SPLIT) {
+        bl0 = wload_lo(0, 0);
+        if (1 / NIT < nchunk) bl1 = wload_lo(0, 1);
+    }
     __builtin_amdgcn_sched_barrier(0);                  // keep the loads ahead of the arithmetic below
     int soff[NPIECE];
 #pragma unroll
@@ -192,7 +228,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         const int r = 16 * m + (lane & 15);
         const int a = r / LM;
         const int j = r - a * LM;
-        aoff[m] = ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;   // bytes
+        aoff[m] = SPLIT ? (2 + a * LP + STRIDE * j + p.off0) * KCP * 4 + 32 * (lane >> 4)          // bytes: 8-channel block
+                        : ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
     }
     v4f acc[NMT];
 #pragma unroll
@@ -219,13 +256,68 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     // the current chunk, so that iteration prefetches the next chunk's first fragments: no fragment-load
     // bubble at chunk boundaries either.  WAR: the image written at (c, NIT-2) was last read at
     // (c-1, NIT-2), i.e. before the barrier of chunk c-1.
-    constexpr bool LEAN = STRIDE == 2;             // stride-2 tiles stage twice the rows (13 pieces/thread): keep ONE
+    constexpr bool LEAN = STRIDE == 2 && !SPLIT;   // stride-2 tiles stage twice the rows (13 pieces/thread): keep ONE
                                                    // fragment buffer there and let the partner wave cover the LDS latency
     constexpr bool XPF = NIT >= 2 && !LEAN;        // cross-chunk fragment prefetch
     constexpr int WIT = XPF ? NIT - 2 : 0;         // iteration after which the next image is written
     constexpr int CUNR = 2;     // chunk pairs: image index and fragment-buffer parity are compile-time, so every
                                 // LDS fragment address is one loop-invariant VGPR + an immediate offset
     const char* ldsb = reinterpret_cast<const char*>(lds);
+    if constexpr (SPLIT) {
+        // Split-precision loop: one iteration = one tap of a 32-channel chunk; per M-tile two ds_read_b128 (hi / lo
+        // plane, for the NEXT iteration) and three fp16 MFMAs (K = 32).  Same chunk pipeline as the fp32 loop.
+        v4f ah[2][NMT], al[2][NMT];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            ah[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m]);
+            al[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + 16);
+        }
+        for (int c0 = 0; c0 < nchunk; c0 += CUNR) {
+#pragma unroll
+            for (int cu = 0; cu < CUNR; ++cu) {
+                const int c = c0 + cu;
+                if (c >= nchunk) break;
+                const int par = XPF ? (cu * NIT) & 1 : 0;
+                const int abase = cu * ABUFP * 4;
+                const int anext = (cu ^ 1) * ABUFP * 4;
+                const bool more = (c + 1 < nchunk);
+                if (!XPF && c > 0) {
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m) {
+                        ah[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase);
+                        al[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase + 16);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int cur = (it + par) & 1;
+                    const h8 bh = __builtin_bit_cast(h8, bq0), bl = __builtin_bit_cast(h8, bl0);
+                    bq0 = bq1; bl0 = bl1;
+                    if (c + (it + 2) / NIT < nchunk) { bq1 = wload_hi(c, it + 2); bl1 = wload_lo(c, it + 2); }
+                    if (it == 0 && more) load_chunk(c + 1);
+                    const bool in_chunk = it + 1 < NIT;
+                    const bool fetch = in_chunk || (XPF && more);
+                    const int src = in_chunk ? abase + (it + 1) * KCP * 4 : anext;
+#pragma unroll
+                    for (int g = 0; g < NMT; ++g) {
+                        if (fetch) {
+                            ah[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + aoff[g] + src);
+                            al[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + aoff[g] + src + 16);
+                        }
+                        const h8 xh = __builtin_bit_cast(h8, ah[cur][g]), xl = __builtin_bit_cast(h8, al[cur][g]);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bl, acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl, bh, acc[g], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (it == WIT && more) {
+                        store_chunk(cu ^ 1);
+                        __syncthreads();
+                    }
+                }
+            }
+        }
+    } else {
     v4f af[2][NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m]);
@@ -278,6 +370,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 #endif
         }
     }
+    }   // exact-fp32 loop
     STAMP(2);
 
     // ---- epilogue mapping: TPP lanes per (agent, group); every lane handles float4 channel vectors of NV rows
@@ -312,11 +405,32 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         if (p.cbias) cbv = *reinterpret_cast<const vec_t*>(p.cbias + (size_t)(b0 + a) * p.cb_stride + n);
         if (p.tbias) tbv = *reinterpret_cast<const vec_t*>(p.tbias + n);
     }
+    // S22 tensors: the 4 channels of a vector sit at (fp32 byte offset) - 2 * (n & 7) in the hi plane, + 16 in the lo plane
+    const int s22_adj = AOUT == 1 ? -2 * (n & 7) : 0;
     vec_t rv[NV];
     if (p.res) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            rv[i] = (i < NV - 1 || last_ok) ? *reinterpret_cast<const vec_t*>(p.res + obase + i * ostep) : vec_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NV; ++i) {
+            if (!(i < NV - 1 || last_ok)) { rv[i] = vec_t{0.f, 0.f, 0.f, 0.f}; continue; }
+            if (AOUT == 1) {
+                // lanes q (channels 8k..8k+3) and q^1 (8k+4..8k+7) share one 8-channel block: the even lane loads its
+                // 16-byte hi plane, the odd lane the lo plane, and they swap halves so each ends up with hi4 + lo4
+                const char* rp = reinterpret_cast<const char*>(p.res + obase + i * ostep) + s22_adj + ((n & 4) ? 8 : 0);
+                const h8 pl = *reinterpret_cast<const h8*>(rp);          // even lane: hi[0..7]; odd lane: lo[0..7]
+                const u4 pw = __builtin_bit_cast(u4, pl);
+                // what the partner needs from me: even lane gives hi[4..7] (words 2,3); odd lane gives lo[0..3] (words 0,1)
+                const unsigned g0 = (n & 4) ? pw[0] : pw[2], g1 = (n & 4) ? pw[1] : pw[3];
+                const unsigned r0 = __shfl_xor((int)g0, 1), r1 = __shfl_xor((int)g1, 1);
+                u2 hw, lw;
+                if (n & 4) { hw = u2{r0, r1}; lw = u2{pw[2], pw[3]}; }   // odd: partner sent hi[4..7]; own lo[4..7]
+                else       { hw = u2{pw[0], pw[1]}; lw = u2{r0, r1}; }   // even: own hi[0..3]; partner sent lo[0..3]
+                const h4 rh = __builtin_bit_cast(h4, hw), rl = __builtin_bit_cast(h4, lw);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[i][e] = (float)rh[e] + (float)rl[e];
+            } else {
+                rv[i] = *reinterpret_cast<const vec_t*>(p.res + obase + i * ostep);
+            }
+        }
     }
 
     __syncthreads();               // every wave is done reading the images before the output tile overwrites them
@@ -345,7 +459,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         const int j = (i < NV - 1 || last_ok) ? RPI * i + jr : jr;      // an empty slot re-reads row jr and is masked below
         const vec_t o = *reinterpret_cast<const vec_t*>(O + (a * LM + j) * OP + ch);
 #pragma unroll
-        for (int e = 0; e < VW; ++e) v[i][e] = vget<VW>(o, e) + vget<VW>(bias, e);
+        for (int e = 0; e < VW; ++e)        // split mode: the weights were scaled by 1 / wscale_inv (a power of two) before splitting
+            v[i][e] = SPLIT ? vget<VW>(o, e) * p.wscale_inv + vget<VW>(bias, e) : vget<VW>(o, e) + vget<VW>(bias, e);
 #pragma unroll
         for (int k = 1; k < KS; ++k) {      // K-split partials, added in rank order
             const vec_t ok = *reinterpret_cast<const vec_t*>(O + k * OTILE + (a * LM + j) * OP + ch);
@@ -399,17 +514,34 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         vec_t o;
 #pragma unroll
         for (int e = 0; e < VW; ++e) vset<VW>(o, e, p.res ? v[i][e] + vget<VW>(rv[i], e) : v[i][e]);
-        if (i < NV - 1 || last_ok)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rsy, yoff + i * ystep, 0, /*aux: sc1*/ 16);
+        if (i < NV - 1 || last_ok) {
+            if (AOUT == 1) {
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = o[e];
+                h4 hh, ll;
+                s22_encode(ov, hh, ll);
+                // even lane stores the block's 16-byte hi plane (own hi4 | partner's hi4), odd lane the lo plane
+                const u2 hw = __builtin_bit_cast(u2, hh), lw = __builtin_bit_cast(u2, ll);
+                const unsigned g0 = (n & 4) ? hw[0] : lw[0], g1 = (n & 4) ? hw[1] : lw[1];
+                const unsigned r0 = __shfl_xor((int)g0, 1), r1 = __shfl_xor((int)g1, 1);
+                const u4 pw = (n & 4) ? u4{r0, r1, lw[0], lw[1]} : u4{hw[0], hw[1], r0, r1};
+                __builtin_amdgcn_raw_buffer_store_b128(pw, rsy, yoff + s22_adj + ((n & 4) ? 8 : 0) + i * ystep, 0, 16);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rsy, yoff + i * ystep, 0, /*aux: sc1*/ 16);
+            }
+        }
     }
     STAMP(6);
     STAMP_RT(9);
 }
 
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
-__global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const ConvArgs p) {
+// register budget: 256 (two waves per SIMD) for the exact-fp32 loop, which needs the partner wave to hide its non-MFMA
+// issue; 512 for the split-precision loop, which keeps two full fragment sets (hi + lo) in flight and is not MFMA-bound
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
+__global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_block_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC>(p, lds, blockIdx.x, blockIdx.y);
+    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT>(p, lds, blockIdx.x, blockIdx.y);
 }
 
 // Two launches that do not depend on each other and share a grid shape, merged into one: blockIdx.z picks the
@@ -419,25 +551,25 @@ __global__ __launch_bounds__(64 * NWN * KS, 2) void conv_block_kernel(const Conv
 // NOT saved -- the second role's workgroups still form their own generation on each CU.
 struct ConvPairArgs { ConvArgs a, b; };
 template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC,
-          int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B>
-__global__ __launch_bounds__(64 * NWN * KS, 2) void conv_pair_kernel(const ConvPairArgs p) {
+          int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT>
+__global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_pair_kernel(const ConvPairArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (interleaving the two roles along x, alone or in XCD-balanced groups of 8, measured 9 % slower end to end)
-    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC>(p.a, lds, blockIdx.x, blockIdx.y);
-    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC>(p.b, lds, blockIdx.x, blockIdx.y);
+    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC, AIN, AOUT>(p.a, lds, blockIdx.x, blockIdx.y);
+    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC, AIN, AOUT>(p.b, lds, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC>
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = MT / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);   // image + dump row
     constexpr int OTILE = KS * MT * (16 * NWN + 4);              // the epilogue's partial output tiles alias the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC>;
+    auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -450,13 +582,13 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B>
+template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_pad, hipStream_t s) {
     constexpr int AG = MT / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);
     constexpr int OTILE = KS * MT * (16 * NWN + 4);
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
-    auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B>;
+    auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -470,34 +602,41 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     return hipGetLastError();
 }
 
-// pairs: (L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B), stride 1 on both sides
+// pairs: (L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT), stride 1 on both sides
 #define CLD_PAIR_INSTANCES(X)                                         \
-    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
-    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
-    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
-    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
-    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
-    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
-    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
-    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)        \
-    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
-    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS)         \
-    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)           \
-    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)           \
-    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)            \
-    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS)
+    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
+    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
+    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
+    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
+    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
+    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
+    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
+    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
+    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
+    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
+    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)           \
+    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)           \
+    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)            \
+    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0) \
+    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 1)   \
+    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
+    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
+    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
+    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)   \
+    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)     \
+    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)
 
 static inline bool pair_is(const ConvGeom& a, const ConvGeom& b, int l_in, int lm, int kc, int nwn, int ks, int gs, int ostr,
-                           int padc, int ntaps_a, int epi_a, int ntaps_b, int epi_b) {
+                           int padc, int ntaps_a, int epi_a, int ntaps_b, int epi_b, int ain, int aout) {
     auto common = [&](const ConvGeom& g) {
         return g.l_in == l_in && g.lm == lm && g.stride == 1 && g.kc == kc && g.nwn == nwn && g.ks == ks && g.gs == gs &&
-               g.ostr == ostr && g.padc == padc;
+               g.ostr == ostr && g.padc == padc && g.ain == ain && g.aout == aout;
     };
     return common(a) && common(b) && a.ntaps == ntaps_a && a.epi == epi_a && b.ntaps == ntaps_b && b.epi == epi_b;
 }
 
 bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b) {
-#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12) if (pair_is(a, b, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12)) return true;
+#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14) if (pair_is(a, b, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14)) return true;
     CLD_PAIR_INSTANCES(X)
 #undef X
     return false;
@@ -505,66 +644,83 @@ bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b) {
 
 hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s) {
     if (a.c_out != b.c_out) return hipErrorInvalidValue;
-#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12) \
-    if (pair_is(ga, gb, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12)) \
-        return launch_pair_inst<c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12>(a, b, b_pad, s);
+#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14) \
+    if (pair_is(ga, gb, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14)) \
+        return launch_pair_inst<c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14>(a, b, b_pad, s);
     CLD_PAIR_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;
 }
 
-// (L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC)
+// (L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT)
 //   tilings: A = (KC 32, NWN 4, KS 1) 64 columns, 4 waves   -- large batches (>= 2 workgroups per CU anyway)
 //            B = (KC 32, NWN 2, KS 2) 32 columns, 4 waves   -- twice the workgroups of A
 //   (the template also supports 8-wave workgroups, e.g. KC 64 / NWN 2 / KS 4; measured slower than B, not built)
 #define CLD_CONV_INSTANCES(X)                            \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1)         \
-    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1)         \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1)            \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1)            \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0)         \
-    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0)         \
-    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0)        \
-    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0)        \
-    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0)        \
-    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0)        \
-    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0)        \
-    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0)        \
-    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0)         \
-    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0)         \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0)            \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0)            \
-    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0)           \
-    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0)           \
-    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0)           \
-    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0)           \
-    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0)           \
-    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0)           \
-    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0)            \
-    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0)            \
-    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0)            \
-    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0)           \
-    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0)           \
-    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0)           \
-    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0)            \
-    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0)
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 0)            \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0)            \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0)            \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0)            \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0)           \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0)           \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 0, 0)           \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0)           \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0)           \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0)           \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0)            \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0)            \
+    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0)            \
+    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0)           \
+    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 0, 0)           \
+    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0)           \
+    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 0, 0)            \
+    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0) \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1)   \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 1)      \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0)   \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 1, 1)  \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 1, 1)     \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
+    X(52, 26, 2, 3, 32, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
+    X(26, 13, 2, 3, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
+    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 1, 1)     \
+    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 1, 1)
 
 static inline bool geom_is(const ConvGeom& g, int l_in, int lm, int stride, int ntaps, int kc, int nwn, int ks,
-                           int epi, int gs, int ostr, int padc) {
+                           int epi, int gs, int ostr, int padc, int ain, int aout) {
     return g.l_in == l_in && g.lm == lm && g.stride == stride && g.ntaps == ntaps && g.kc == kc &&
-           g.nwn == nwn && g.ks == ks && g.epi == epi && g.gs == gs && g.ostr == ostr && g.padc == padc;
+           g.nwn == nwn && g.ks == ks && g.epi == epi && g.gs == gs && g.ostr == ostr && g.padc == padc &&
+           g.ain == ain && g.aout == aout;
 }
 
 bool conv_geom_supported(const ConvGeom& g) {
-#define X(a, b, c, d, e, f, k, h, i, j, l) if (geom_is(g, a, b, c, d, e, f, k, h, i, j, l)) return true;
+#define X(a, b, c, d, e, f, k, h, i, j, l, m, n) if (geom_is(g, a, b, c, d, e, f, k, h, i, j, l, m, n)) return true;
     CLD_CONV_INSTANCES(X)
 #undef X
     return false;
 }
 
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
-#define X(a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_) \
-    if (geom_is(g, a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_)) return launch_inst<a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_>(a, b_pad, s);
+#define X(a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_) \
+    if (geom_is(g, a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_)) return launch_inst<a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_>(a, b_pad, s);
     CLD_CONV_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;

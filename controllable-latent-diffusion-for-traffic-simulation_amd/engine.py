@@ -25,7 +25,8 @@ class Engine:
     """Owns a `cld_handle`.  Weights come in under the reference's state_dict names."""
 
     def __init__(self, n_timesteps: int = 100, device="cuda:0", dynamics: Optional[Mapping] = None,
-                 norm_info=None, step_time: float = 0.1):
+                 norm_info=None, step_time: float = 0.1, precision: str = "f32"):
+        """precision: "f32" (exact fp32 MFMA) or "f16x2" (fp16 hi/lo split operands, fp32 accumulate; include/cld.h)."""
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -36,6 +37,9 @@ class Engine:
         self.lib.cld_default_config(C.byref(cfg))
         cfg.n_timesteps = int(n_timesteps)
         cfg.step_time = float(step_time)
+        if precision not in _lib.PRECISIONS:
+            raise CldError(f"unknown precision '{precision}' (f32 | f16x2)")
+        cfg.precision = _lib.PRECISIONS[precision]
         if dynamics is not None:      # config.yaml:134-141
             if "acce_bound" in dynamics:
                 cfg.acce_bound[0], cfg.acce_bound[1] = map(float, dynamics["acce_bound"])
@@ -56,6 +60,7 @@ class Engine:
             raise CldError(f"cld_create failed ({rc})")
         self._ws = None
         self._finalized = False
+        self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(self.lib.cld_get_precision(self._h))]
         n = self.n_timesteps
         xc, nc, lv = (np.empty(n, np.float32) for _ in range(3))
         self._check(self.lib.cld_get_schedule(self._h, xc.ctypes.data, nc.ctypes.data, lv.ctypes.data), "cld_get_schedule")

@@ -59,7 +59,16 @@ typedef struct cld_config {
     float max_yawvel;       /* 2*pi          config.yaml:137                          */
     float norm_mean[6];     /* config.yaml:162  (x - mean) / std convention,          */
     float norm_std[6];      /* config.yaml:163   models/vae/vae_model.py:152,170      */
+    int32_t precision;      /* arithmetic of the U-Net convolutions, CLD_PRECISION_*; no reference counterpart */
 } cld_config;
+
+/* CLD_PRECISION_F32   : exact fp32 products on v_mfma_f32_16x16x4_f32 (default).
+ * CLD_PRECISION_F16X2 : every activation and weight is carried as two fp16 planes hi + lo (22 mantissa bits in the
+ *                       same 4 bytes), products hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32
+ *                       accumulation; GroupNorm / Mish / residuals / the DDPM update stay fp32.  The first convolution
+ *                       (4-channel latent, unbounded range) keeps the exact-fp32 loop.  Values saturate at +-65504.
+ *                       Same parity bars as F32 (tests run both); ~2x the throughput. */
+enum { CLD_PRECISION_F32 = 0, CLD_PRECISION_F16X2 = 1 };
 
 /* Fill `cfg` with the reference defaults listed above. */
 void cld_default_config(cld_config* cfg);
@@ -183,6 +192,9 @@ int cld_profile_read(cld_handle h, double* total_ms /*HOST*/, int64_t* launches 
 /* Diagnostic builds only (-DCLD_STAMPS; a no-op in the shipped library): conv launch number `layer`
  * (0..36) of every following U-Net evaluation writes 16 u64 cycle stamps per workgroup into `buf`. */
 int cld_debug_stamps(cld_handle h, void* buf /*DEVICE, u64[16 * workgroups]*/, int32_t layer);
+
+/* CLD_PRECISION_* the handle runs with. */
+int cld_get_precision(cld_handle h);
 
 /* Library build id (for the "native code loaded" check). */
 const char* cld_version(void);

@@ -16,9 +16,12 @@ NBUF_OFF = 3 * 208 + 1792          # floats per agent before the activation buff
 ACT = 3328
 
 
+PRECISION = __import__("os").environ.get("CLD_TEST_PRECISION", "f32")     # the whole file runs per precision mode
+
+
 def _engine(n=100, jitter=True, decoder=True):
     from cld_amd.engine import Engine
-    e = Engine(n_timesteps=n, device="cuda:0")
+    e = Engine(n_timesteps=n, device="cuda:0", precision=PRECISION)
     e.load_state_dict(synth.make_unet_weights(0, affine_jitter=jitter))
     if decoder:
         e.load_state_dict(synth.make_decoder_weights(0))
@@ -40,7 +43,13 @@ def _buf(e, B, idx, C, L):
     bp = (B + 15) // 16 * 16
     ws = e._ws.view(torch.float32)
     off = bp * NBUF_OFF + idx * bp * ACT
-    return ws[off: off + bp * ACT].reshape(bp, L, C)[:B].permute(0, 2, 1).cpu().numpy()
+    raw = ws[off: off + bp * ACT]
+    if e.precision == "f16x2" and idx != 7:      # S22 activations: per 8-channel block [8 x fp16 hi][8 x fp16 lo]
+        h = raw.view(torch.float16).reshape(bp, L, C // 8, 2, 8).float()
+        val = (h[:, :, :, 0] + h[:, :, :, 1]).reshape(bp, L, C)
+    else:
+        val = raw.reshape(bp, L, C)
+    return val[:B].permute(0, 2, 1).cpu().numpy()
 
 
 @pytest.mark.parametrize("tag", ["default", "jitter"])
