@@ -219,7 +219,8 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     *g = l.g;
     const long waves_a = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64) * 4;
     auto set = [&](int kc, int nwn, int ks) { g->kc = kc; g->nwn = nwn; g->ks = ks; return true; };
-    if (l.g.ain == 1) return l.has_a ? set(32, 4, 1) : false;  // split-precision loop: 64-column tiling only (no K split)
+    if (l.g.ain == 1)      // split-precision loop: 64-column tiling only (no K split); 64-channel chunks where the images fit
+        return l.has_a ? set(l.g.stride == 2 ? 32 : 64, 4, 1) : false;
     static const char* force = getenv("CLD_TILING");            // experiments only: A / B
     if (force && force[0] == 'A' && l.has_a) return set(32, 4, 1);
     if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
@@ -501,6 +502,7 @@ int cld_finalize(cld_handle h, void* stream) {
         l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0, ain, aout};
         if (c2 > 0 && c2 != c1_real) return fail(h, CLD_ERR_ARG, "cld_finalize: concatenated sources must have equal channel counts");
         ConvGeom t = l.g;
+        if (ain == 1 && stride == 1) t.kc = 64;
         l.has_a = conv_geom_supported(t);
         t.nwn = 2; t.ks = 2;
         l.has_b = conv_geom_supported(t);

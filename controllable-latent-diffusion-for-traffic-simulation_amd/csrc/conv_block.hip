@@ -112,7 +112,8 @@ __device__ __forceinline__ void s22_encode(const float (&v)[4], h4& hi, h4& lo) 
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const int bx, const int by) {
     constexpr bool SPLIT = AIN == 1;
-    static_assert(!SPLIT || (KS == 1 && KC == 32 && PADC == 0), "split-precision loop: one 32-channel MFMA K per chunk, no K split");
+    static_assert(!SPLIT || (KS == 1 && KC % 32 == 0 && PADC == 0), "split-precision loop: whole 32-channel MFMA groups, no K split");
+    constexpr int MG = KC / 32;            // split mode: 32-channel MFMA groups per chunk
     constexpr int NTHR = 64 * NWN * KS;
     constexpr int AG = MT / LM;            // agents per workgroup
     constexpr int LP = L_IN + 2;           // LDS rows per agent (2 halo rows shared with the neighbour)
@@ -130,7 +131,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     constexpr int PPR = KC / 4;            // 16-byte pieces per staged row
     constexpr int NPC = IN_ROWS * PPR;
     constexpr int NPIECE = (NPC + NTHR - 1) / NTHR;
-    constexpr int NIT = (AIN == 1) ? NTAPS : NTAPS * KGW;   // iterations per chunk per wave: (tap, 16-channel group), or taps in split mode (one MFMA spans the chunk)
+    constexpr int NIT = (AIN == 1) ? NTAPS * MG : NTAPS * KGW;   // iterations per chunk per wave: (tap, 16-channel group); split mode: (tap, 32-channel MFMA group)
     static_assert(NTHR % PPR == 0, "a thread keeps one channel piece");
 
     const int tid = threadIdx.x;
@@ -193,12 +194,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     };
 
     // split mode: slab (32-channel chunk c, tap t, N tile) = [hi: 64 lanes x 8 fp16][lo: 64 lanes x 8 fp16] = 2 KiB
-    auto wload_hi = [&](int c, int it) {
-        return buf_load16(rsw, wlane, (((c + it / NIT) * NTAPS + it % NIT) * ntn + ntile_g) * 2048);
+    auto wslab = [&](int c, int it) {                   // iteration it of chunk c = (tap it / MG, group it % MG)
+        const int cc = c + it / NIT, ii = it % NIT;
+        return (((cc * MG + ii % MG) * NTAPS + ii / MG) * ntn + ntile_g) * 2048;
     };
-    auto wload_lo = [&](int c, int it) {
-        return buf_load16(rsw, wlane, (((c + it / NIT) * NTAPS + it % NIT) * ntn + ntile_g) * 2048 + 1024);
-    };
+    auto wload_hi = [&](int c, int it) { return buf_load16(rsw, wlane, wslab(c, it)); };
+    auto wload_lo = [&](int c, int it) { return buf_load16(rsw, wlane, wslab(c, it) + 1024); };
 
     // ---- prologue: chunk 0 and the first weight fragments go out first; the LDS-side address arithmetic
     //      (divisions by the row counts), the accumulator clear and the halo zeroing run under their latency ----
@@ -220,16 +221,26 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         const int r = ok ? idx / PPR : tid / PPR;
         const int a = r / L_IN;
         const int l = r - a * L_IN;
-        soff[i] = ok ? (2 + a * LP + l) * KCP + pc4 : AROWS * KCP + pc4;
+        // split mode: odd LDS rows keep the hi / lo planes of every 8-channel block swapped, so the two lanes of a
+        // 16-lane read group that land on one 32-byte slot (rows 5 apart mod 8) take different 16-byte halves
+        const int pcs = SPLIT ? (pc4 ^ (((2 + a * LP + l) & 1) << 2)) : pc4;
+        soff[i] = ok ? (2 + a * LP + l) * KCP + pcs : AROWS * KCP + pc4;
     }
     int aoff[NMT];
+    int aoffy[SPLIT ? NMT : 1];                         // split mode: aoff = plane at +0/+16 for even taps, aoffy = the other plane
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
         const int r = 16 * m + (lane & 15);
         const int a = r / LM;
         const int j = r - a * LM;
-        aoff[m] = SPLIT ? (2 + a * LP + STRIDE * j + p.off0) * KCP * 4 + 32 * (lane >> 4)          // bytes: 8-channel block
-                        : ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
+        if (SPLIT) {
+            const int row = 2 + a * LP + STRIDE * j + p.off0;      // LDS row of tap 0
+            const int blk = row * KCP * 4 + 32 * (lane >> 4);      // bytes: this lane's 8-channel block
+            aoff[m] = blk + ((row & 1) ? 16 : 0);                  // hi plane on even taps, lo plane on odd taps
+            aoffy[m] = blk + ((row & 1) ? 0 : 16);
+        } else {
+            aoff[m] = ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
+        }
     }
     v4f acc[NMT];
 #pragma unroll
@@ -270,7 +281,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
             ah[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m]);
-            al[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + 16);
+            al[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoffy[m]);
         }
         for (int c0 = 0; c0 < nchunk; c0 += CUNR) {
 #pragma unroll
@@ -285,7 +296,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 #pragma unroll
                     for (int m = 0; m < NMT; ++m) {
                         ah[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase);
-                        al[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase + 16);
+                        al[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoffy[m] + abase);
                     }
                 }
 #pragma unroll
@@ -297,12 +308,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
                     if (it == 0 && more) load_chunk(c + 1);
                     const bool in_chunk = it + 1 < NIT;
                     const bool fetch = in_chunk || (XPF && more);
-                    const int src = in_chunk ? abase + (it + 1) * KCP * 4 : anext;
+                    const int tn = in_chunk ? (it + 1) / MG : 0, gn = in_chunk ? (it + 1) % MG : 0;   // next iteration's tap / group
+                    const int src = (in_chunk ? abase : anext) + tn * KCP * 4 + gn * 128;
 #pragma unroll
                     for (int g = 0; g < NMT; ++g) {
-                        if (fetch) {
-                            ah[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + aoff[g] + src);
-                            al[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + aoff[g] + src + 16);
+                        if (fetch) {       // the planes trade places on odd taps (row parity flips with the tap offset)
+                            ah[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + ((tn & 1) ? aoffy[g] : aoff[g]) + src);
+                            al[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + ((tn & 1) ? aoff[g] : aoffy[g]) + src);
                         }
                         const h8 xh = __builtin_bit_cast(h8, ah[cur][g]), xl = __builtin_bit_cast(h8, al[cur][g]);
                         acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh, bh, acc[g], 0, 0, 0);
@@ -619,12 +631,12 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)            \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0) \
     X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 1)   \
-    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
-    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
-    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
-    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)   \
-    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)     \
-    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)
+    X(26, 26, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
+    X(13, 13, 64, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
+    X(13, 13, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
+    X(26, 26, 64, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)   \
+    X(13, 13, 64, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)     \
+    X(26, 26, 64, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)
 
 static inline bool pair_is(const ConvGeom& a, const ConvGeom& b, int l_in, int lm, int kc, int nwn, int ks, int gs, int ostr,
                            int padc, int ntaps_a, int epi_a, int ntaps_b, int epi_b, int ain, int aout) {
@@ -689,20 +701,20 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1)   \
     X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 1)      \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0)   \
-    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
-    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 1, 1)  \
-    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
-    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
-    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
-    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 1, 1)     \
-    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
-    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
+    X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
+    X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0)   \
+    X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
+    X(13, 13, 1, 5, 64, 4, 1, EPI_GN_MISH, 32, 1, 0, 1, 1)  \
+    X(13, 13, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
+    X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
+    X(26, 26, 1, 1, 64, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
+    X(13, 13, 1, 1, 64, 4, 1, EPI_BIAS, 32, 1, 0, 1, 1)     \
+    X(13, 13, 1, 1, 64, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
+    X(26, 26, 1, 1, 64, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
     X(52, 26, 2, 3, 32, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
     X(26, 13, 2, 3, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
-    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 1, 1)     \
-    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 1, 1)
+    X(13, 13, 1, 2, 64, 4, 1, EPI_BIAS, 16, 2, 0, 1, 1)     \
+    X(26, 26, 1, 2, 64, 4, 1, EPI_BIAS, 8, 2, 0, 1, 1)
 
 static inline bool geom_is(const ConvGeom& g, int l_in, int lm, int stride, int ntaps, int kc, int nwn, int ks,
                            int epi, int gs, int ostr, int padc, int ain, int aout) {
