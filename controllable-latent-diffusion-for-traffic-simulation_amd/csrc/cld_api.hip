@@ -40,6 +40,7 @@ struct ConvLayer {
 };
 
 struct ResBlock { ConvLayer c0, c1, res; bool has_res = false; };
+const char* const kResnet = "context_encoder.map_encoder.encoder_heads.map_model.";
 
 }  // namespace
 
@@ -60,6 +61,12 @@ struct cld_handle_s {
     DecoderWeights dec{};
     EncoderWeights enc{};
     bool has_encoder = false;
+    // ContextEncoder (optional): stem, 19 NHWC convolutions, head
+    struct Conv2dLayer { float *wfrag = nullptr, *scale = nullptr, *shift = nullptr; int kh = 3, stride = 1, hin = 56, cin = 64, cout = 64; };
+    bool has_context = false;
+    float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
+    Conv2dLayer rn_conv[4][2][2], rn_ds[4];
+    ContextHeadArgs ctx_head{};
     DynParams dyn{};
     // optional HIP-event timing of the dominant conv kernel instance (k5 GN+Mish block -> 256 channels, L = 13)
     bool prof_on = false;
@@ -131,6 +138,39 @@ void add_expect(cld_handle h) {
     e["lstm_enc.cond2hidden.weight"] = 64 * 256; e["lstm_enc.cond2hidden.bias"] = 64;
     e["mu.weight"] = 4 * 64;     e["mu.bias"] = 4;
     e["logvar.weight"] = 4 * 64; e["logvar.bias"] = 4;
+    // ContextEncoder (models/context_utils.py:8-38): two base_models.MLP (`_model` Sequential: Linear, LayerNorm, ReLU, ...)
+    // and torchvision resnet18 under map_encoder.encoder_heads.map_model (base_models.py:559-614)
+    auto mlp = [&](const std::string& p, int d_in, std::initializer_list<int> hidden, int d_out) {
+        int i = 0, d = d_in;
+        for (int hd : hidden) {
+            lin(p + "._model." + std::to_string(i), hd, d);
+            gn(p + "._model." + std::to_string(i + 1), hd);        // LayerNorm weight / bias
+            i += 3; d = hd;
+        }
+        lin(p + "._model." + std::to_string(i), d_out, d);
+    };
+    auto bn = [&](const std::string& p, int c) {
+        e[p + ".weight"] = c; e[p + ".bias"] = c; e[p + ".running_mean"] = c; e[p + ".running_var"] = c;
+    };
+    mlp("context_encoder.agent_state_encoder", 4, {64, 64}, 64);
+    mlp("context_encoder.process_cond_mlp", 320, {320, 320, 256, 256}, 256);
+    const std::string r = kResnet;
+    e[r + "conv1.weight"] = (size_t)64 * 34 * 49;
+    bn(r + "bn1", 64);
+    int cin = 64;
+    for (int li = 1; li <= 4; ++li) {
+        const int c = 32 << li;
+        for (int b = 0; b < 2; ++b) {
+            const std::string p = r + "layer" + std::to_string(li) + "." + std::to_string(b);
+            e[p + ".conv1.weight"] = (size_t)c * (b == 0 ? cin : c) * 9;
+            bn(p + ".bn1", c);
+            e[p + ".conv2.weight"] = (size_t)c * c * 9;
+            bn(p + ".bn2", c);
+            if (b == 0 && cin != c) { e[p + ".downsample.0.weight"] = (size_t)c * cin; bn(p + ".downsample.1", c); }
+        }
+        cin = c;
+    }
+    lin(r + "fc", 256, 512);
 }
 
 // dm_model.py:29-56 + diffuser_helpers.py:451-462, same op order in fp32
@@ -453,6 +493,7 @@ int cld_load_weight(cld_handle h, const char* name, const float* data, size_t nu
                                   "x_t_cof", "noise_cof"};
     for (const char* sname : sched)
         if (k == sname) return CLD_OK;     // rebuilt from n_timesteps by cld_create
+    if (k.size() > 20 && k.compare(k.size() - 20, 20, ".num_batches_tracked") == 0) return CLD_OK;   // BatchNorm counter: unused in eval
     auto it = h->expect.find(k);
     if (it == h->expect.end()) return fail(h, CLD_ERR_ARG, "cld_load_weight: unknown key '" + k + "'");
     if (it->second != numel)
@@ -645,6 +686,89 @@ int cld_finalize(cld_handle h, void* stream) {
         UP(tmp, *getw(h, "mu.bias")); h->enc.b_mu = tmp;
         UP(tmp, *getw(h, "logvar.weight")); h->enc.w_lv = tmp;
         UP(tmp, *getw(h, "logvar.bias")); h->enc.b_lv = tmp;
+    }
+    // ---- ContextEncoder (optional) -----------------------------------------------------------
+    h->has_context = true;
+    for (const auto& kv : h->expect)
+        if (kv.first.rfind("context_encoder.", 0) == 0 && !h->w.count(kv.first)) h->has_context = false;
+    if (h->has_context) {
+        // eval-mode BatchNorm2d folded to y = x * scale + shift (eps 1e-5, torchvision resnet.py norm_layer default)
+        auto fold_bn = [&](const std::string& p, float** scale, float** shift) -> int {
+            const std::vector<float>&g = *getw(h, p + ".weight"), &b = *getw(h, p + ".bias"), &m = *getw(h, p + ".running_mean"),
+                                    &v = *getw(h, p + ".running_var");
+            std::vector<float> sc(g.size()), sh(g.size());
+            for (size_t i = 0; i < g.size(); ++i) {
+                const double k = (double)g[i] / std::sqrt((double)v[i] + 1e-5);
+                sc[i] = (float)k;
+                sh[i] = (float)((double)b[i] - (double)m[i] * k);
+            }
+            UP(*scale, sc);
+            UP(*shift, sh);
+            return CLD_OK;
+        };
+        const std::string r = kResnet;
+        {   // stem: per input plane c the 49 taps are 13 MFMA k-steps (k = 4 q + (lane >> 4)); lane holds 4 k-steps per float4
+            const std::vector<float>& W = *getw(h, r + "conv1.weight");     // [64][34][7][7]
+            std::vector<float> wq((size_t)34 * 4 * 4 * 64 * 4);
+            size_t o = 0;
+            for (int c = 0; c < 34; ++c)
+                for (int qg = 0; qg < 4; ++qg)
+                    for (int nt = 0; nt < 4; ++nt)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int sidx = 0; sidx < 4; ++sidx) {
+                                const int k = 4 * (4 * qg + sidx) + (lane >> 4);
+                                wq[o++] = k < 49 ? W[((size_t)(16 * nt + (lane & 15)) * 34 + c) * 49 + k] : 0.f;
+                            }
+            UP(h->stem_w, wq);
+            if ((rc = fold_bn(r + "bn1", &h->stem_scale, &h->stem_shift)) != CLD_OK) return rc;
+        }
+        auto make2d = [&](cld_handle_s::Conv2dLayer& l, const std::string& wname, const std::string& bnname, int kh, int stride,
+                          int hin, int cin, int cout) -> int {
+            const std::vector<float>& W = *getw(h, wname);                  // [cout][cin][kh][kh]
+            auto wget = [&](int co, int ci, int t) -> float { return W[((size_t)co * cin + ci) * kh * kh + t]; };
+            std::vector<float> packed = pack_conv_weights(wget, cout, cin, kh * kh);
+            UP(l.wfrag, packed);
+            l.kh = kh; l.stride = stride; l.hin = hin; l.cin = cin; l.cout = cout;
+            return fold_bn(bnname, &l.scale, &l.shift);
+        };
+        int cin = 64, hin = 56;
+        for (int li = 1; li <= 4; ++li) {
+            const int c = 32 << li;
+            for (int b = 0; b < 2; ++b) {
+                const std::string p = r + "layer" + std::to_string(li) + "." + std::to_string(b);
+                const int stride = (b == 0 && li > 1) ? 2 : 1;
+                const int hout = hin / stride;
+                if ((rc = make2d(h->rn_conv[li - 1][b][0], p + ".conv1.weight", p + ".bn1", 3, stride, hin, b == 0 ? cin : c, c))) return rc;
+                if ((rc = make2d(h->rn_conv[li - 1][b][1], p + ".conv2.weight", p + ".bn2", 3, 1, hout, c, c))) return rc;
+                if (b == 0 && cin != c)
+                    if ((rc = make2d(h->rn_ds[li - 1], p + ".downsample.0.weight", p + ".downsample.1", 1, 2, hin, cin, c))) return rc;
+                hin = hout;
+            }
+            cin = c;
+        }
+        // head: transposed Linear weights [in][out]
+        auto upT = [&](const std::string& wname, const float** dst) -> int {
+            const std::vector<float>& W = *getw(h, wname);
+            const std::string bname = wname.substr(0, wname.size() - 6) + "bias";
+            const size_t n_out = getw(h, bname)->size(), n_in = W.size() / n_out;
+            std::vector<float> t(W.size());
+            for (size_t o = 0; o < n_out; ++o)
+                for (size_t i = 0; i < n_in; ++i) t[i * n_out + o] = W[o * n_in + i];
+            float* d; UP(d, t); *dst = d;
+            return CLD_OK;
+        };
+        auto up1 = [&](const std::string& name, const float** dst) -> int { float* d; UP(d, *getw(h, name)); *dst = d; return CLD_OK; };
+        ContextHeadArgs& a = h->ctx_head;
+        if ((rc = upT(r + "fc.weight", &a.fc_wt)) || (rc = up1(r + "fc.bias", &a.fc_b))) return rc;
+        const std::string sp = "context_encoder.agent_state_encoder._model.", cp = "context_encoder.process_cond_mlp._model.";
+        for (int i = 0; i < 3; ++i) {
+            if ((rc = upT(sp + std::to_string(3 * i) + ".weight", &a.s_wt[i])) || (rc = up1(sp + std::to_string(3 * i) + ".bias", &a.s_b[i]))) return rc;
+            if (i < 2 && ((rc = up1(sp + std::to_string(3 * i + 1) + ".weight", &a.s_g[i])) || (rc = up1(sp + std::to_string(3 * i + 1) + ".bias", &a.s_be[i])))) return rc;
+        }
+        for (int i = 0; i < 5; ++i) {
+            if ((rc = upT(cp + std::to_string(3 * i) + ".weight", &a.c_wt[i])) || (rc = up1(cp + std::to_string(3 * i) + ".bias", &a.c_b[i]))) return rc;
+            if (i < 4 && ((rc = up1(cp + std::to_string(3 * i + 1) + ".weight", &a.c_g[i])) || (rc = up1(cp + std::to_string(3 * i + 1) + ".bias", &a.c_be[i])))) return rc;
+        }
     }
 #undef UP
     HIPCK(h, hipStreamSynchronize(s));     // host staging vectors die with this scope
@@ -855,6 +979,60 @@ int cld_state_to_state_and_action(cld_handle h, const float* positions, const fl
         return fail(h, CLD_ERR_ARG, "cld_state_to_state_and_action: bad argument");
     HIPCK(h, launch_state_to_state_action(h->dyn, positions, yaws, curr_speed, out6, B, scaled_output,
                                           static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+// ---- ContextEncoder ---------------------------------------------------------------------------------------
+namespace {
+constexpr int kCtxChunk = 256;                               // agents per pass: bounds the activation scratch
+constexpr size_t kStemFloats = (size_t)112 * 112 * 64;       // per agent
+constexpr size_t kActFloats = (size_t)56 * 56 * 64;          // largest post-pool activation per agent
+}
+size_t cld_context_workspace_bytes(cld_handle h, int32_t B) {
+    if (!h || B < 1) return 0;
+    const size_t cb = (size_t)(B < kCtxChunk ? B : kCtxChunk);
+    return cb * (kStemFloats + 3 * kActFloats) * sizeof(float);
+}
+
+int cld_context_encode(cld_handle h, const float* image, const float* curr_states, float* cond_feat, float* map_feat,
+                       int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!h->finalized || !h->has_context) return fail(h, CLD_ERR_STATE, "cld_context_encode: context_encoder weights not loaded");
+    if (!image || !curr_states || !cond_feat || B < 1) return fail(h, CLD_ERR_ARG, "cld_context_encode: bad argument");
+    if (!workspace || workspace_bytes < cld_context_workspace_bytes(h, B))
+        return fail(h, CLD_ERR_WORKSPACE, "cld_context_encode: workspace too small");
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 || reinterpret_cast<uintptr_t>(image) % 16)
+        return fail(h, CLD_ERR_ARG, "cld_context_encode: image and workspace must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cb = B < kCtxChunk ? B : kCtxChunk;
+    float* y1 = static_cast<float*>(workspace);
+    float* buf[3];
+    for (int i = 0; i < 3; ++i) buf[i] = y1 + (size_t)cb * kStemFloats + (size_t)i * cb * kActFloats;
+    auto run = [&](const cld_handle_s::Conv2dLayer& l, const float* x, const float* res, float* y, int relu, int n) {
+        return launch_conv2d(l.kh, l.stride, l.hin, x, l.wfrag, l.scale, l.shift, res, y, n, l.cin, l.cout, relu, s);
+    };
+    for (int b0 = 0; b0 < B; b0 += cb) {
+        const int n = (B - b0) < cb ? (B - b0) : cb;
+        HIPCK(h, launch_stem_conv(image + (size_t)b0 * 34 * 224 * 224, h->stem_w, h->stem_scale, h->stem_shift, y1, n, s));
+        HIPCK(h, launch_maxpool(y1, buf[0], n, s));
+        int xi = 0;                                            // buffer holding the current block input
+        for (int li = 0; li < 4; ++li)
+            for (int b = 0; b < 2; ++b) {                      // BasicBlock: relu(bn2(conv2(relu(bn1(conv1 x)))) + identity)
+                const int ti = (xi + 1) % 3, yi = (xi + 2) % 3;
+                HIPCK(h, run(h->rn_conv[li][b][0], buf[xi], nullptr, buf[ti], 1, n));
+                if (b == 0 && li > 0) {                        // identity = bn(conv1x1/2 x); x's buffer is free afterwards
+                    HIPCK(h, run(h->rn_ds[li], buf[xi], nullptr, buf[yi], 0, n));
+                    HIPCK(h, run(h->rn_conv[li][b][1], buf[ti], buf[yi], buf[xi], 1, n));
+                } else {
+                    HIPCK(h, run(h->rn_conv[li][b][1], buf[ti], buf[xi], buf[yi], 1, n));
+                    xi = yi;
+                }
+            }
+        ContextHeadArgs a = h->ctx_head;
+        a.feat = buf[xi]; a.curr_states = curr_states + (size_t)b0 * 4; a.cond_out = cond_feat + (size_t)b0 * 256;
+        a.map_feat_out = map_feat ? map_feat + (size_t)b0 * 256 : nullptr; a.B = n;
+        HIPCK(h, launch_context_head(a, s));
+    }
     return CLD_OK;
 }
 

@@ -138,4 +138,26 @@ hipError_t launch_state_to_state_action(const DynParams& d, const float* pos, co
 hipError_t launch_world_step(const float* traj, const float* centroid, const float* yaw, int k, float* world,
                              float* next_cs, int B, hipStream_t s);
 
+// ---- ContextEncoder (models/context_utils.py:8-61; context_kernels.hip) ------------------------------------
+// stem: image [B,34,224,224] NCHW -> y [B,112,112,64] NHWC = ReLU(BN(conv 7x7/2)); wq: packed by pack_stem_weights
+hipError_t launch_stem_conv(const float* image, const float* wq, const float* scale, const float* shift, float* y, int B,
+                            hipStream_t s);
+// MaxPool2d(3, 2, 1): [B,112,112,64] -> [B,56,56,64] (NHWC)
+hipError_t launch_maxpool(const float* x, float* y, int B, hipStream_t s);
+// NHWC conv (kh = 3: pad 1, stride 1 | 2; kh = 1: stride 2) + folded BatchNorm [+ residual] [+ ReLU];
+// hin = input height = width in {56, 28, 14, 7}; wfrag in pack_conv_weights layout (tap = kh * KW + kw)
+hipError_t launch_conv2d(int kh, int stride, int hin, const float* x, const float* wfrag, const float* scale,
+                         const float* shift, const float* res, float* y, int B, int cin, int cout, int relu, hipStream_t s);
+struct ContextHeadArgs {
+    const float* feat;          // [B,7,7,512] NHWC, layer4 output
+    const float* curr_states;   // [B,4]
+    float* cond_out;            // [B,256]
+    float* map_feat_out;        // [B,256] or null (diagnostic tap: the fc output)
+    int B;
+    const float *fc_wt, *fc_b;  // transposed weights [in][out] throughout
+    const float *s_wt[3], *s_b[3], *s_g[2], *s_be[2];     // agent_state_encoder: 4 -> 64 -> 64 -> 64
+    const float *c_wt[5], *c_b[5], *c_g[4], *c_be[4];     // process_cond_mlp: 320 -> 320 -> 320 -> 256 -> 256 -> 256
+};
+hipError_t launch_context_head(const ContextHeadArgs& a, hipStream_t s);
+
 }  // namespace cld

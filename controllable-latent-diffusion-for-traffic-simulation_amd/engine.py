@@ -59,6 +59,7 @@ class Engine:
         if rc != 0:
             raise CldError(f"cld_create failed ({rc})")
         self._ws = None
+        self._ctx_ws = None
         self._finalized = False
         self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(self.lib.cld_get_precision(self._h))]
         n = self.n_timesteps
@@ -229,6 +230,23 @@ class Engine:
                                                                int(scaled_output), self._stream()),
                         "cld_state_to_state_and_action")
         return out
+
+    def context_encode(self, image, curr_states, want_map_feat=False):
+        """ContextEncoder.forward (models/context_utils.py:40-61): image [B,34,224,224] NCHW, curr_states [B,4]
+        -> cond_feat [B,256] (and the resnet18 fc output [B,256] when `want_map_feat`)."""
+        image = self._f32(image)
+        B = image.shape[0]
+        image = self._f32(image, (B, 34, 224, 224)); cs = self._f32(curr_states, (B, 4))
+        cond = torch.empty(B, COND, dtype=torch.float32, device=self.device)
+        mf = torch.empty(B, 256, dtype=torch.float32, device=self.device) if want_map_feat else None
+        need = int(self.lib.cld_context_workspace_bytes(self._h, B))
+        if self._ctx_ws is None or self._ctx_ws.numel() < need:
+            self._ctx_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_context_encode(self._h, _ptr(image), _ptr(cs), _ptr(cond), _ptr(mf), B,
+                                                    C.c_void_p(self._ctx_ws.data_ptr()), C.c_size_t(self._ctx_ws.numel()),
+                                                    self._stream()), "cld_context_encode")
+        return (cond, mf) if want_map_feat else cond
 
     def world_step(self, traj, centroid, yaw, k: int):
         """env_trajdata.py:452-468 for plan step k -> (world [B,3] = (x, y, h), next curr_states [B,4])."""

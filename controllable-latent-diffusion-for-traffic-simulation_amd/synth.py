@@ -261,3 +261,107 @@ def make_noise(B: int, steps: int, seed: int = 123) -> dict:
     xT = normal(seed, "x_T", (B, HORIZON, LATENT))
     z = normal(seed, "step_noise", (steps, B, HORIZON, LATENT))
     return {"x_T": xT, "noise": z}
+
+
+# --------------------------------------------------------------------------- #
+# ContextEncoder: models/context_utils.py:8-61
+# --------------------------------------------------------------------------- #
+RASTER_C, RASTER_HW = 34, 224      # 31 history planes + 3 semantic planes (trajdata_utils.py:409-420,536-544); config.yaml:81
+STATE_FEAT = 64                    # config.yaml:119 curr_state_feat_dim
+MAP_FEAT = 256                     # config.yaml:120 map_feature_dim
+CTX = "context_encoder."
+RESNET = CTX + "map_encoder.encoder_heads.map_model."     # MapEncoder -> feature extractor -> RasterizedMapEncoder.map_model
+
+
+def context_shapes() -> "OrderedDict[str, tuple]":
+    """state_dict entries of VaeModel.context_encoder: the two MLPs (base_models.py:21-96: `_model` =
+    Sequential(Linear, LayerNorm, ReLU, ..., Linear)) and torchvision's resnet18 with the 34-channel conv1 and the
+    512 -> 256 fc that RasterizedMapEncoder installs (base_models.py:559-614).  `num_batches_tracked` entries are
+    omitted (integers, unused in eval)."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def mlp(p, d_in, hidden, d_out):
+        i, d = 0, d_in
+        for h in hidden:
+            s[f"{p}._model.{i}.weight"] = (h, d); s[f"{p}._model.{i}.bias"] = (h,)
+            s[f"{p}._model.{i + 1}.weight"] = (h,); s[f"{p}._model.{i + 1}.bias"] = (h,)      # LayerNorm
+            i += 3
+            d = h
+        s[f"{p}._model.{i}.weight"] = (d_out, d); s[f"{p}._model.{i}.bias"] = (d_out,)
+
+    def bn(p, c):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{p}.{k}"] = (c,)
+
+    mlp(CTX + "agent_state_encoder", 4, (STATE_FEAT, STATE_FEAT), STATE_FEAT)
+    r = RESNET
+    s[r + "conv1.weight"] = (64, RASTER_C, 7, 7)
+    bn(r + "bn1", 64)
+    cin = 64
+    for li, c in enumerate((64, 128, 256, 512), start=1):
+        for b in range(2):
+            p = f"{r}layer{li}.{b}"
+            s[p + ".conv1.weight"] = (c, cin if b == 0 else c, 3, 3)
+            bn(p + ".bn1", c)
+            s[p + ".conv2.weight"] = (c, c, 3, 3)
+            bn(p + ".bn2", c)
+            if b == 0 and cin != c:
+                s[p + ".downsample.0.weight"] = (c, cin, 1, 1)
+                bn(p + ".downsample.1", c)
+        cin = c
+    s[r + "fc.weight"] = (MAP_FEAT, 512)
+    s[r + "fc.bias"] = (MAP_FEAT,)
+    n = STATE_FEAT + MAP_FEAT
+    mlp(CTX + "process_cond_mlp", n, (n, n, COND, COND), COND)
+    return s
+
+
+def make_context_weights(seed: int = 0, stat_jitter: bool = True) -> "OrderedDict[str, np.ndarray]":
+    """Random ContextEncoder weights.  Convolutions: He-style U(+-sqrt(6/fan_in)) (keeps activations O(1) through the
+    20 layers); Linear: PyTorch default.  With `stat_jitter` the BatchNorm running statistics / affine and the LayerNorm
+    affine are randomised so that eval-mode BN and LN arithmetic is exercised (default init would make BN an identity)."""
+    shapes = context_shapes()
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in shapes.items():
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "running_mean":
+            out[name] = uniform(seed, name, shape, -0.2, 0.2) if stat_jitter else np.zeros(shape, np.float32)
+        elif leaf == "running_var":
+            out[name] = uniform(seed, name, shape, 0.5, 1.5) if stat_jitter else np.ones(shape, np.float32)
+        elif len(shape) == 4:
+            bound = np.sqrt(6.0 / (shape[1] * shape[2] * shape[3]))
+            out[name] = uniform(seed, name, shape, -bound, bound)
+        elif len(shape) == 2:
+            bound = 1.0 / np.sqrt(shape[1])
+            out[name] = uniform(seed, name, shape, -bound, bound)
+        else:   # 1-D: Linear bias, or BN / LN affine
+            wname = name[: -len(leaf)] + "weight"
+            if leaf == "bias" and len(shapes[wname]) == 2:
+                bound = 1.0 / np.sqrt(shapes[wname][1])
+                out[name] = uniform(seed, name, shape, -bound, bound)
+            elif leaf == "weight":
+                out[name] = uniform(seed, name, shape, 0.7, 1.3) if stat_jitter else np.ones(shape, np.float32)
+            else:
+                out[name] = uniform(seed, name, shape, -0.2, 0.2) if stat_jitter else np.zeros(shape, np.float32)
+    return out
+
+
+def make_raster(B: int, seed: int = 1, dense: bool = False) -> np.ndarray:
+    """Synthetic `image` [B,34,224,224] with the reference raster's structure (trajdata_utils.py:123-156,409-420):
+    planes 0..30 are history frames that are zero except a +1 pixel trail (the agent) and a few -1 pixels
+    (neighbours); planes 31..33 are semantic layers in [0,1] (here smooth random blobs thresholded).  `dense`
+    fills every plane with U(-1,1) instead (worst case for a data-dependent kernel; used by parity tests)."""
+    if dense:
+        return uniform(seed, "raster_dense", (B, RASTER_C, RASTER_HW, RASTER_HW), -1.0, 1.0)
+    img = np.zeros((B, RASTER_C, RASTER_HW, RASTER_HW), np.float32)
+    nb = 6
+    px = uniform(seed, "raster_px", (B, 31, 1 + nb, 2), 8.0, RASTER_HW - 8.0).astype(np.int64)
+    b_idx = np.arange(B)[:, None]
+    p_idx = np.arange(31)[None, :]
+    img[b_idx, p_idx, px[:, :, 0, 1], px[:, :, 0, 0]] = 1.0
+    for k in range(1, 1 + nb):
+        img[b_idx, p_idx, px[:, :, k, 1], px[:, :, k, 0]] = -1.0
+    coarse = uniform(seed, "raster_sem", (B, 3, 14, 14), 0.0, 1.0)
+    sem = np.repeat(np.repeat(coarse, 16, axis=2), 16, axis=3)
+    img[:, 31:34] = (sem > 0.5).astype(np.float32)
+    return img

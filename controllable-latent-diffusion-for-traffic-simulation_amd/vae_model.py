@@ -3,7 +3,7 @@
 `VaeModel.convert_action_to_state_and_action / scale_traj / descale_traj`
 (models/vae/vae_model.py:100-173), as used at
 src/trainers/guide_dm_trainer.py:97-98,195-196,210-211.
-`traj2z` (the encoder) is built too; `ContextEncoder` (f-1) is not.
+`traj2z` (the encoder) and `ContextEncoder` / `pre_vae` (f-1, context_utils.py) are built too.
 """
 from __future__ import annotations
 
@@ -11,6 +11,7 @@ from typing import Optional
 
 import torch
 
+from .context_utils import ContextEncoder
 from .dm_model import cfg_get
 from .engine import Engine
 
@@ -36,6 +37,7 @@ class VaeModel:
         self.engine = engine or Engine(device=device, dynamics=cfg_get(algo_config, "dynamics"),
                                        norm_info=cfg_get(algo_config, "nusc_norm_info.diffuser"))
         self.lstmvae = LSTMVAE(self.engine)
+        self.context_encoder = ContextEncoder(self.engine)
         self.default_chosen_inds = [0, 1, 2, 3, 4, 5]
         self.dt = 0.1
         c = self.engine.cfg
@@ -45,6 +47,12 @@ class VaeModel:
     def load_state_dict(self, sd, strict=True):
         self.engine.load_state_dict(sd, strict=strict)
         return self
+
+    def pre_vae(self, batch):
+        """vae_model.py:84-88 -> (aux_info, state_and_action_scaled, state_and_action)."""
+        aux_info = self.context_encoder(batch)
+        sa = self.get_state_and_action_from_data_batch(batch, scaled=False)
+        return aux_info, self.get_state_and_action_from_data_batch(batch, scaled=True), sa
 
     def convert_action_to_state_and_action(self, x_out, curr_states, scaled_input=True, descaled_output=False):
         four_d = x_out.dim() == 4          # vae_model.py:108-111

@@ -172,6 +172,20 @@ int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const fl
 int cld_state_to_state_and_action(cld_handle h, const float* positions, const float* yaws, const float* curr_speed,
                                   float* out6, int32_t B, int32_t scaled_output, void* stream);
 
+/* aux_info['cond_feat'] = ContextEncoder.forward(data_batch)  (models/context_utils.py:40-61):
+ *   process_cond_mlp([agent_state_encoder(curr_states) | map_encoder(image)])
+ * image [B,34,224,224] fp32 NCHW (data_batch['image']: 31 history planes + 3 semantic planes,
+ * src/tbsim/utils/trajdata_utils.py:409-420), read in place -- no re-layout pass; curr_states [B,4] = (x, y, v, yaw) as
+ * batch_utils.get_current_states builds them (src/tbsim/utils/batch_utils.py:46-65); cond_feat [B,256];
+ * map_feat [B,256] optional (NULL to skip): the resnet18 'fc' output MapEncoder returns (diffuser_helpers.py:313-341).
+ * The map branch is torchvision's resnet18 (eval-mode BatchNorm) with the 34-channel stem and the 512 -> 256 fc of
+ * RasterizedMapEncoder (src/tbsim/models/base_models.py:559-614).  Weights: "context_encoder.*" keys of
+ * VaeModel.state_dict() (a leading "vae." is accepted); "*.num_batches_tracked" entries are ignored.
+ * Agents are processed in passes of <= 256, so the scratch (cld_context_workspace_bytes) is bounded by ~1.4 GB. */
+size_t cld_context_workspace_bytes(cld_handle h, int32_t B);
+int cld_context_encode(cld_handle h, const float* image, const float* curr_states, float* cond_feat, float* map_feat,
+                       int32_t B, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Closed-loop kinematic update of EnvUnifiedSimulation._step (src/tbsim/envs/env_trajdata.py:452-468) for plan step k
  * (the last of the n_step_action executed steps): traj [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate) in the agent frame
  * at planning time, centroid [B,2], yaw [B] (world pose at planning time) -> world [B,3] = (x, y, h) with

@@ -344,5 +344,70 @@ def traj2z(w: Dict[str, Tensor], x6: Tensor, cond: Tensor, noise: Optional[Tenso
 # --------------------------------------------------------------------------- #
 # helpers for tests / bench
 # --------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------- #
+# f-1  ContextEncoder (models/context_utils.py:8-61)
+# --------------------------------------------------------------------------- #
+CTX = "context_encoder."
+RESNET = CTX + "map_encoder.encoder_heads.map_model."
+
+
+def mlp_ln(w: Dict[str, Tensor], p: str, x: Tensor, n_hidden: int) -> Tensor:
+    """src/tbsim/models/base_models.py:21-96 with normalization=True: n_hidden x (Linear -> LayerNorm -> ReLU), then a
+    last Linear; `_model` is the nn.Sequential, so the state_dict indices step by 3."""
+    i = 0
+    for _ in range(n_hidden):
+        x = F.linear(x, w[f"{p}._model.{i}.weight"], w[f"{p}._model.{i}.bias"])
+        x = F.layer_norm(x, (x.shape[-1],), w[f"{p}._model.{i + 1}.weight"], w[f"{p}._model.{i + 1}.bias"], 1e-5)
+        x = F.relu(x)
+        i += 3
+    return F.linear(x, w[f"{p}._model.{i}.weight"], w[f"{p}._model.{i}.bias"])
+
+
+def _bn(w, p, x):
+    # eval-mode BatchNorm2d (running statistics, eps 1e-5): torchvision resnet.py BasicBlock / ResNet._forward_impl
+    return F.batch_norm(x, w[p + ".running_mean"], w[p + ".running_var"], w[p + ".weight"], w[p + ".bias"], False, 0.0, 1e-5)
+
+
+def resnet18_features(w: Dict[str, Tensor], image: Tensor, taps: Optional[dict] = None) -> Tensor:
+    """The map_model of RasterizedMapEncoder (src/tbsim/models/base_models.py:559-614): torchvision 0.20 `resnet18()`
+    (third-party, absent here: restated from its published definition, torchvision/models/resnet.py -- conv1 7x7/2 ->
+    BN -> ReLU -> maxpool 3x3/2 -> 4 stages of 2 BasicBlocks [conv3x3 -> BN -> ReLU -> conv3x3 -> BN, + identity or
+    1x1/2 conv + BN, ReLU] -> adaptive avg-pool -> fc) with conv1 replaced by Conv2d(34, 64, 7, 2, 3, bias=False) and
+    fc by Linear(512, 256).  MapEncoder reads the 'map_model.fc' node of the feature extractor
+    (diffuser_helpers.py:313-341), i.e. the fc output BEFORE RasterizedMapEncoder's output ReLU.  Parity of this
+    function is UNPINNED (no torchvision to run the reference's own module)."""
+    r = RESNET
+    x = F.conv2d(image, w[r + "conv1.weight"], None, stride=2, padding=3)
+    x = F.relu(_bn(w, r + "bn1", x))
+    if taps is not None:
+        taps["stem"] = x
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li in range(1, 5):
+        for b in range(2):
+            p = f"{r}layer{li}.{b}"
+            stride = 2 if (b == 0 and li > 1) else 1
+            idt = x
+            y = F.relu(_bn(w, p + ".bn1", F.conv2d(x, w[p + ".conv1.weight"], None, stride=stride, padding=1)))
+            y = _bn(w, p + ".bn2", F.conv2d(y, w[p + ".conv2.weight"], None, stride=1, padding=1))
+            if (p + ".downsample.0.weight") in w:
+                idt = _bn(w, p + ".downsample.1", F.conv2d(x, w[p + ".downsample.0.weight"], None, stride=stride))
+            x = F.relu(y + idt)
+        if taps is not None:
+            taps[f"layer{li}"] = x
+    x = x.mean(dim=(2, 3))
+    return F.linear(x, w[r + "fc.weight"], w[r + "fc.bias"])
+
+
+def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, taps: Optional[dict] = None) -> Tensor:
+    """ContextEncoder.forward (models/context_utils.py:40-61): cond_feat = process_cond_mlp(
+    [agent_state_encoder(curr_states) | map_encoder(image)]) -> [B,256].  curr_states [B,4] = (x, y, v, yaw)
+    as batch_utils.get_current_states builds them (src/tbsim/utils/batch_utils.py:46-65)."""
+    sf = mlp_ln(w, CTX + "agent_state_encoder", curr_states, 2)
+    mf = resnet18_features(w, image, taps)
+    if taps is not None:
+        taps["state_feat"], taps["map_feat"] = sf, mf
+    return mlp_ln(w, CTX + "process_cond_mlp", torch.cat([sf, mf], dim=-1), 4)
+
+
 def to_torch(d: dict, dtype=torch.float32) -> Dict[str, Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in d.items()}

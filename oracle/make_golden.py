@@ -138,6 +138,48 @@ def section_encoder(ref):
          state_action=x6, z=z, mu=mu, logvar=lv)
 
 
+def section_context(ref):
+    """ContextEncoder row.  The reference's own ContextEncoder.forward (models/context_utils.py:40-61)
+    runs unmodified -- its agent_state_encoder / process_cond_mlp (base_models.MLP), batch_utils.get_current_states and the
+    concatenation order -- with ONE substitution: `map_encoder` (torchvision resnet18, absent here) is replaced by a
+    callable that returns the oracle's restatement of it, recorded as `map_feat`.  So this fixture pins everything
+    around the ResNet; the ResNet-18 arithmetic itself stays unpinned."""
+    from models.context_utils import ContextEncoder
+    from tbsim.utils.batch_utils import set_global_batch_type
+    from oracle import cld_oracle as O
+    set_global_batch_type("trajdata")
+    B = 4
+    dyn = ref.dynamics.Unicycle("dynamics", max_steer=ref.algo.dynamics["max_steer"], max_yawvel=ref.algo.dynamics["max_yawvel"],
+                                acce_bound=ref.algo.dynamics["acce_bound"])
+    ce = _refimport.quiet(ContextEncoder, 4, ref.algo, {"image": (34, 224, 224)}, dyn).eval()
+    w = synth.make_context_weights(W_SEED)
+    sd = {k: v for k, v in ce.state_dict().items()}
+    for k, v in w.items():
+        kk = k[len("context_encoder."):]
+        if kk.startswith("map_encoder."):
+            continue
+        assert tuple(sd[kk].shape) == v.shape, (kk, sd[kk].shape, v.shape)
+        sd[kk] = T(v)
+    ce.load_state_dict(sd, strict=False)
+    img = T(synth.make_raster(B, IN_SEED, dense=True))
+    hist_pos = T(synth.normal(IN_SEED, "hist_pos", (B, 31, 2)))
+    hist_yaw = T(synth.normal(IN_SEED, "hist_yaw", (B, 31, 1)) * 0.3)
+    speed = T(synth.uniform(IN_SEED, "curr_speed", (B,), 0.0, 15.0))
+    with torch.no_grad():
+        map_feat = O.resnet18_features(O.to_torch(w), img)
+
+        class _Map(torch.nn.Module):                             # the one substitution
+            def forward(self, image):
+                return map_feat, None
+        ce.map_encoder = _Map()
+        out = ce({"history_positions": hist_pos, "history_yaws": hist_yaw, "curr_speed": speed, "image": img})
+        state_feat = ce.agent_state_encoder(out["curr_states"])
+    save("context", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "raster": "synth.make_raster(B, in_seed, dense=True)",
+                     "history": "normal(in_seed,'hist_pos'|'hist_yaw'*0.3), uniform(in_seed,'curr_speed',0,15)",
+                     "map_encoder": "oracle.resnet18_features (torchvision absent: unpinned)"},
+         curr_states=out["curr_states"], state_feat=state_feat, map_feat=map_feat, cond_feat=out["cond_feat"])
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -145,10 +187,11 @@ def main():
     algo = ref.algo
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
-            {"cfg": section_cfg, "encoder": section_encoder}[name](ref)
+            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
+    section_context(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

@@ -206,3 +206,60 @@ def test_encoder_row_golden(golden):
     # decoder absent on this handle: the call reports it instead of crashing
     with pytest.raises(Exception):
         e.lstm_decode(z, cond)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f-1  ContextEncoder (models/context_utils.py:8-61)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def eng_ctx():
+    from cld_amd.engine import Engine
+    e = Engine(n_timesteps=10, device="cuda:0")
+    e.load_state_dict(synth.make_unet_weights(0))
+    e.load_state_dict(synth.make_context_weights(0))
+    return e.finalize()
+
+
+def test_context_encoder_golden(golden, eng_ctx):
+    """cond_feat against the reference's ContextEncoder.forward (MLPs / concat from the reference, ResNet-18 from the
+    oracle's restatement: torchvision is absent, so the map branch itself is parity-unpinned).  Bars: 1e-4 relative on
+    the fc output (|.| ~ 60), 1e-4 abs on cond_feat (|.| ~ 1)."""
+    from cld_amd.context_utils import ContextEncoder
+    meta, g = golden("context")
+    B = meta["B"]
+    batch = {"history_positions": torch.from_numpy(synth.normal(meta["in_seed"], "hist_pos", (B, 31, 2))),
+             "history_yaws": torch.from_numpy(synth.normal(meta["in_seed"], "hist_yaw", (B, 31, 1)) * 0.3),
+             "curr_speed": torch.from_numpy(synth.uniform(meta["in_seed"], "curr_speed", (B,), 0.0, 15.0)),
+             "image": torch.from_numpy(synth.make_raster(B, meta["in_seed"], dense=True)).cuda()}
+    aux = ContextEncoder(eng_ctx)(batch)
+    assert set(aux) == {"cond_feat", "curr_states", "image"}
+    assert np.array_equal(aux["curr_states"].cpu().numpy(), g["curr_states"])
+    _, mf = eng_ctx.context_encode(batch["image"], aux["curr_states"], want_map_feat=True)
+    scale = float(np.abs(g["map_feat"]).max())
+    assert np.abs(mf.cpu().numpy() - g["map_feat"]).max() <= 1e-4 * scale
+    assert np.abs(aux["cond_feat"].cpu().numpy() - g["cond_feat"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("B,dense", [(5, True), (3, False)])
+def test_context_encoder_vs_oracle(eng_ctx, B, dense):
+    """Ragged agent counts (tiles of 2 / 4 agents at 14x14 / 7x7) and the sparse raster (zero-strip shortcut of the stem)."""
+    from oracle import cld_oracle as O
+    img = torch.from_numpy(synth.make_raster(B, 7, dense=dense))
+    cs = torch.from_numpy(synth.make_inputs(B, 7)["curr_states"])
+    cond, mf = eng_ctx.context_encode(img.cuda(), cs.cuda(), want_map_feat=True)
+    taps = {}
+    ref = O.context_encode(O.to_torch(synth.make_context_weights(0)), img, cs, taps)
+    scale = float(taps["map_feat"].abs().max())
+    assert (mf.cpu() - taps["map_feat"]).abs().max().item() <= 1e-4 * scale
+    assert (cond.cpu() - ref).abs().max().item() <= 1e-4
+
+
+def test_context_encoder_agents_are_independent(eng_ctx):
+    """Size-independent property: every agent's cond_feat depends on its own raster / state only, so a 261-agent batch
+    (two passes of <= 256 agents, ragged tiles) built by repeating 3 agents must reproduce their rows bit for bit."""
+    img3 = torch.from_numpy(synth.make_raster(3, 11, dense=False)).cuda()
+    cs3 = torch.from_numpy(synth.make_inputs(3, 11)["curr_states"]).cuda()
+    c3 = eng_ctx.context_encode(img3, cs3)
+    idx = torch.arange(261, device="cuda") % 3
+    big = eng_ctx.context_encode(img3[idx], cs3[idx])
+    assert torch.equal(big, c3[idx])

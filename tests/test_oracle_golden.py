@@ -155,3 +155,29 @@ def test_encoder_row(golden):
     z, mu, lv = O.traj2z(w, x6s, cond, nz)
     for got, k in ((z, "z"), (mu, "mu"), (lv, "logvar")):
         assert np.abs(got.numpy() - g[k]).max() <= 1e-5, k
+
+
+def test_context_encoder_around_the_resnet(golden):
+    """f-1: the reference's own ContextEncoder.forward (its MLPs, get_current_states, concat order) recorded with the
+    oracle's ResNet-18 restatement substituted for the absent torchvision module (make_golden.section_context).
+    Pins mlp_ln / the composition; the ResNet arithmetic is pinned only to this container's torch conv2d (regression)."""
+    meta, g = golden("context")
+    B = meta["B"]
+    w = O.to_torch(synth.make_context_weights(meta["w_seed"]))
+    cs = torch.zeros(B, 4)
+    cs[:, :2] = torch.from_numpy(synth.normal(meta["in_seed"], "hist_pos", (B, 31, 2)))[:, -1]
+    cs[:, 2] = torch.from_numpy(synth.uniform(meta["in_seed"], "curr_speed", (B,), 0.0, 15.0))
+    cs[:, 3] = torch.from_numpy(synth.normal(meta["in_seed"], "hist_yaw", (B, 31, 1)) * 0.3)[:, -1, 0]
+    assert np.array_equal(cs.numpy(), g["curr_states"])
+    sf = O.mlp_ln(w, O.CTX + "agent_state_encoder", cs, 2)
+    assert np.abs(sf.numpy() - g["state_feat"]).max() <= 2e-6
+    cond = O.mlp_ln(w, O.CTX + "process_cond_mlp", torch.cat([sf, torch.from_numpy(g["map_feat"])], dim=-1), 4)
+    assert np.abs(cond.numpy() - g["cond_feat"]).max() <= 5e-6
+    img = torch.from_numpy(synth.make_raster(B, meta["in_seed"], dense=True))
+    torch.set_num_threads(8)
+    taps = {}
+    full = O.context_encode(w, img, cs, taps)
+    torch.set_num_threads(1)
+    scale = float(np.abs(g["map_feat"]).max())
+    assert np.abs(taps["map_feat"].numpy() - g["map_feat"]).max() <= 1e-5 * scale      # thread-count spread of torch's conv2d
+    assert np.abs(full.numpy() - g["cond_feat"]).max() <= 2e-5
