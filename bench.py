@@ -29,6 +29,8 @@ if ROOT not in sys.path:
 
 FLOP_PER_STEP_AGENT = 119_232_512          # U-Net forward, SURVEY 8(d) / BASELINE.md section 2
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2516.6              # MI355X_MICROARCH.md: v_mfma_f32_16x16x32_f16 dense peak (f16x2 mode issues 3 MFMAs per product)
+FLOP_PER_CONTEXT_AGENT = 2 * 3_031_000_000   # ResNet-18 on [34,224,224] (stem 1.337 GMAC) + fc + MLPs, SURVEY 8(f-1)
 
 
 def main():
@@ -46,6 +48,8 @@ def main():
                          "e.g. --closed-loop 20 --denoise-steps 50 --scenes 64 --agents 64")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
                     help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split operands with fp32 accumulation (include/cld.h)")
+    ap.add_argument("--no-context", action="store_true",
+                    help="skip the ContextEncoder (producer of cond_feat, SURVEY 8(f-1)) measurement / closed-loop stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     args = ap.parse_args()
@@ -83,6 +87,8 @@ def main():
     eng = Engine(n_timesteps=n, device=dev, precision=args.precision)
     eng.load_state_dict(synth.make_unet_weights(0))            # PyTorch-default-like random init (no checkpoint ships)
     eng.load_state_dict(synth.make_decoder_weights(0))
+    if not args.no_context:
+        eng.load_state_dict(synth.make_context_weights(0))
     eng.finalize()
 
     # synthetic inputs, resident in HBM before the timed region starts
@@ -98,13 +104,29 @@ def main():
 
     world0 = torch.zeros(B, 3, device=dev)
 
+    use_ctx = not args.no_context
+    if use_ctx:
+        # synthetic raster with the reference's structure (trajdata_utils.py:123-156,409-420): 31 history planes that are
+        # zero except a +1 agent pixel and a few -1 neighbour pixels, 3 semantic planes of 0/1 blobs; resident in HBM
+        raster = torch.zeros(B, 34, 224, 224, device=dev)
+        px = torch.randint(8, 216, (B, 31, 7, 2), device=dev, generator=g)
+        bi = torch.arange(B, device=dev)[:, None, None].expand(B, 31, 7)
+        pi = torch.arange(31, device=dev)[None, :, None].expand(B, 31, 7)
+        val = torch.full((B, 31, 7), -1.0, device=dev)
+        val[:, :, 0] = 1.0
+        raster[bi, pi, px[..., 1], px[..., 0]] = val
+        sem = (torch.rand(B, 3, 14, 14, device=dev, generator=g) > 0.5).float()
+        raster[:, 31:] = sem.repeat_interleave(16, dim=2).repeat_interleave(16, dim=3)
+        del px, bi, pi, val, sem
+
     def one_step():
         if args.closed_loop:      # rollout loop of env_utils.py:255-304 kept on the device (policy.closed_loop_rollout)
             world, c = world0, cs
             for _ in range(args.closed_loop):
-                x0, _, _ = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w,
+                cnd = eng.context_encode(raster, c) if use_ctx else cond      # obs -> cond_feat (context_utils.py:40-61)
+                x0, _, _ = eng.sample(x_T, cnd, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w,
                                       want_x1=False, want_logp=False)
-                traj = eng.decode(x0, cond, c, descaled_output=True)
+                traj = eng.decode(x0, cnd, c, descaled_output=True)
                 if distributed:
                     gather_trajectories(traj, gathered)
                 world, c = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), 4)
@@ -142,8 +164,12 @@ def main():
         eng.profile_enable(False)
         if launches > 0 and ms > 0:
             ach = flop / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
+            split = args.precision == "f16x2"      # 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi) per algorithmic product
+            peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": pmc_traffic(B) if not split else None,
+                    "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
+                                   else "v_mfma_f32_16x16x4_f32 dense peak"),
                     "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0> (Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; "
                                "7 launches per U-Net evaluation; tiling picked by batch size)"
                                % ("4,1" if (B + 15) // 16 * 4 * 4 >= 2048 else "2,2")),
@@ -156,7 +182,8 @@ def main():
         "metric": "denoising-step·agent/s", "value": round(value, 1), "unit": "step·agent/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x2 (fp16 hi+lo operand split, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]" if (args.scenes, args.agents, args.cfg_w, args.closed_loop) == (32, 32, 0.0, 0) else "custom")
                                + (f" closed loop, {args.closed_loop} sim steps per bench step, each" if args.closed_loop else "")
                                + f": {args.scenes} scenes x {args.agents} agents per GPU, {n} denoising steps "
@@ -169,11 +196,37 @@ def main():
         "scenes_per_s": round(world * args.scenes * args.steps / dt, 2),
         "unet_tflops_effective": round(value * FLOP_PER_STEP_AGENT * (2 if args.cfg_w else 1) / 1e12, 2),
         "roofline_whole_path_frac": round(value * FLOP_PER_STEP_AGENT * (2 if args.cfg_w else 1) / 1e12
-                                          / (PEAK_F32_MFMA_TFLOPS * world), 4),
+                                          / ((PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0) * world), 4),
     }
     if roof:
         out["roofline"] = roof
 
+    if use_ctx and not args.closed_loop:
+        # ContextEncoder measured on its own (it runs once per planning call, not per denoising step): B agents, rasters
+        # resident in HBM.  Twice: on the structured raster (the stem skips all-zero strips of the near-empty history planes,
+        # so fewer FLOPs are executed than the dense count) and on a dense U(-1,1) raster (every MFMA issued: the honest
+        # fraction of the fp32-MFMA peak).
+        def time_ctx():
+            eng.context_encode(raster, cs)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                eng.context_encode(raster, cs)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / 3
+        t_struct = time_ctx()
+        raster.uniform_(-1.0, 1.0, generator=g)
+        t_dense = time_ctx()
+        tf_dense = B * FLOP_PER_CONTEXT_AGENT / t_dense / 1e12
+        out["context_encoder"] = {
+            "agents": B, "agents_per_s": round(B / t_struct, 1), "ms": round(t_struct * 1e3, 3),
+            "raster_read_GBps": round(B * 34 * 224 * 224 * 4 / t_struct / 1e9, 1),
+            "dense_raster": {"agents_per_s": round(B / t_dense, 1), "ms": round(t_dense * 1e3, 3), "tflops": round(tf_dense, 2),
+                             "frac_of_f32_mfma_peak": round(tf_dense / PEAK_F32_MFMA_TFLOPS, 4)},
+            "flop_per_agent_dense": FLOP_PER_CONTEXT_AGENT,
+            "note": "resnet18 [34,224,224] -> 256 + state / combine MLPs (models/context_utils.py:8-61), exact fp32 MFMA; "
+                    "headline = structured synthetic raster (31 near-empty history planes + 3 semantic planes, "
+                    "trajdata_utils.py:409-420); bound: MFMA (the 6.8 MB raster per agent is read once, in place)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:

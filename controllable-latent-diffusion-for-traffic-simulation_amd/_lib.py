@@ -29,6 +29,13 @@ class CldConfig(C.Structure):
 
 
 PRECISIONS = {"f32": 0, "f16x2": 1}
+OPTIMIZERS = {"adam": 0, "sgd": 1}
+
+
+class CldGuidance(C.Structure):
+    """include/cld.h `cld_guidance` (device pointers + optimiser settings of the sampling-time guidance step)."""
+    _fields_ = [("curr_states", C.c_void_p), ("target_speed", C.c_void_p), ("loss_scale", C.c_void_p),
+                ("lr", C.c_float), ("perturb_th", C.c_float), ("optimizer", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -46,6 +53,9 @@ SIGNATURES = {
     "cld_ddpm_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.c_size_t, _P]),
     "cld_sample": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
     "cld_sample_cfg": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
+    "cld_sample_guided": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.POINTER(CldGuidance), C.c_int32, _P, _P, _P, C.c_int32,
+                                    C.c_uint64, _P, C.c_size_t, _P]),
+    "cld_guidance_step": (C.c_int, [_P, _P, _P, C.POINTER(CldGuidance), C.c_float, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_log_prob": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_lstm_decode": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
     "cld_action_to_state": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),

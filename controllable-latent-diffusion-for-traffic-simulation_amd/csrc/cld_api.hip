@@ -270,9 +270,9 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
 }
 
 struct Ws {
-    float *xw, *xtmp, *meanb, *cb, *buf[NBUF];
+    float *xw, *xtmp, *meanb, *cb, *buf[NBUF], *guide;
 };
-size_t ws_floats(int b_pad) { return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT); }
+size_t ws_floats(int b_pad) { return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT) + guide_scratch_floats(b_pad); }
 Ws carve(void* ws, int b_pad) {
     Ws w;
     float* p = static_cast<float*>(ws);
@@ -281,6 +281,7 @@ Ws carve(void* ws, int b_pad) {
     w.meanb = p; p += (size_t)b_pad * T * D;
     w.cb = p; p += (size_t)b_pad * NCB;
     for (int i = 0; i < NBUF; ++i) { w.buf[i] = p; p += (size_t)b_pad * ACT; }
+    w.guide = p;       // activations kept by the guidance kernel's LSTM forward (guide_scratch_floats)
     return w;
 }
 inline int pad16(int b) { return (b + 15) / 16 * 16; }
@@ -876,44 +877,101 @@ int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* 
     return CLD_OK;
 }
 
-int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
-                   float guidance_w, int32_t steps, float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
-                   void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_common(h, "cld_sample_cfg", 2 * pad16(B), 0, workspace, workspace_bytes);
+static int sample_impl(cld_handle h, const char* fn, const float* x_T, const float* noise, const float* cond,
+                       const float* non_cond, float guidance_w, const cld_guidance* gd, int32_t steps, float* x0, float* x1,
+                       float* logp, int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
+    const bool cfg = non_cond != nullptr;
+    int rc = check_common(h, fn, cfg ? 2 * pad16(B) : B, 0, workspace, workspace_bytes);
     if (rc) return rc;
-    if (!x_T || !cond || !non_cond) return fail(h, CLD_ERR_ARG, "cld_sample_cfg: null pointer");
+    if (!x_T || !cond) return fail(h, CLD_ERR_ARG, std::string(fn) + ": null pointer");
     if (steps != h->cfg.n_timesteps)
-        return fail(h, CLD_ERR_ARG, "cld_sample_cfg: steps must equal n_timesteps (the reference sampler has stride 1)");
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal n_timesteps (the reference sampler has stride 1)");
+    if (gd) {
+        if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
+        if (!gd->curr_states || !gd->target_speed) return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and target_speed");
+        if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // one 2B-agent batch per step: rows [0, bp) carry cond_feat, rows [bp, 2bp) the unconditional features,
+    // CFG: one 2B-agent batch per step: rows [0, bp) carry cond_feat, rows [bp, 2bp) the unconditional features,
     // both halves the same latent; the head combines the two noise predictions and rewrites both halves.
-    const int bp = pad16(B), bp2 = 2 * bp;
-    Ws w = carve(workspace, bp2);
+    const int bp = pad16(B), bpn = cfg ? 2 * bp : bp;
+    Ws w = carve(workspace, bpn);
     float* x_hi = w.xw + (size_t)bp * T * D;
     HIPCK(h, launch_pack_latent(x_T, w.xw, B, bp, s));
-    HIPCK(h, launch_pack_latent(x_T, x_hi, B, bp, s));
     HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
-    HIPCK(h, launch_cond_bias(non_cond, h->wc, h->cbias_b, w.cb + (size_t)bp * NCB, B, bp, NCB, s));
+    if (cfg) {
+        HIPCK(h, launch_pack_latent(x_T, x_hi, B, bp, s));
+        HIPCK(h, launch_cond_bias(non_cond, h->wc, h->cbias_b, w.cb + (size_t)bp * NCB, B, bp, NCB, s));
+    }
     for (int it = 0; it < steps; ++it) {
         const int i = steps - 1 - it;
-        HIPCK(h, run_unet(h, w, w.xw, i, bp2, s));
+        HIPCK(h, run_unet(h, w, w.xw, i, bpn, s));
         const float sigma = std::exp(0.5f * h->plvc[i]);
+        const bool guide = gd && i > 0;       // upstream defaults: apply_guidance_intermediate, not apply_guidance_output
         HeadArgs a{};
-        a.f = w.buf[7]; a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w;
-        a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
+        a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
+        if (cfg) { a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w; }
         a.z = noise ? noise + (size_t)it * B * T * D : nullptr;
         a.seed = seed; a.step_salt = (unsigned long long)it;
-        a.x_out = w.xw; a.x_out2 = x_hi;
-        a.mean_out = (i == 0) ? w.meanb : nullptr;
         a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
         a.sg = (i == 0) ? 0.f : sigma;
+        if (guide) {
+            a.mean_out = w.meanb;                            // the guidance kernel perturbs the mean and adds the noise
+        } else {
+            a.x_out = w.xw;                                  // in place: each thread rewrites the row it read
+            a.x_out2 = cfg ? x_hi : nullptr;
+            a.mean_out = (i == 0) ? w.meanb : nullptr;
+        }
         HIPCK(h, launch_head(a, s));
+        if (guide) {
+            GuideArgs g{};
+            g.mean = w.meanb; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed;
+            g.loss_scale = gd->loss_scale; g.z = a.z; g.x_out = w.xw; g.x_out2 = cfg ? x_hi : nullptr;
+            g.scratch = w.guide; g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
+            g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
+            HIPCK(h, launch_guide(h->dec, h->dyn, g, s));
+        }
         if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
         if (i == 0) {
             if (x0) HIPCK(h, launch_unpack(w.xw, x0, B, s));
             if (logp) HIPCK(h, launch_logprob(w.xw, w.meanb, sigma, logp, B, s));
         }
     }
+    return CLD_OK;
+}
+
+int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
+                   float guidance_w, int32_t steps, float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (h && !non_cond) return fail(h, CLD_ERR_ARG, "cld_sample_cfg: null pointer");
+    return sample_impl(h, "cld_sample_cfg", x_T, noise, cond, non_cond, guidance_w, nullptr, steps, x0, x1, logp, B, seed,
+                       workspace, workspace_bytes, stream);
+}
+
+int cld_sample_guided(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
+                      float guidance_w, const cld_guidance* guidance, int32_t steps, float* x0, float* x1, float* logp,
+                      int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
+    if (h && !guidance) return fail(h, CLD_ERR_ARG, "cld_sample_guided: null guidance");
+    return sample_impl(h, "cld_sample_guided", x_T, noise, cond, non_cond, guidance_w, guidance, steps, x0, x1, logp, B, seed,
+                       workspace, workspace_bytes, stream);
+}
+
+int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const cld_guidance* gd, float sigma, const float* z,
+                      float* mean_guided, float* x_next, float* grad, int32_t B, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    int rc = check_common(h, "cld_guidance_step", B, 0, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_guidance_step: decoder weights not loaded");
+    if (!mean || !cond || !gd || !gd->curr_states || !gd->target_speed || (x_next && sigma != 0.f && !z))
+        return fail(h, CLD_ERR_ARG, "cld_guidance_step: null pointer");
+    if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, "cld_guidance_step: unknown optimizer");
+    Ws w = carve(workspace, pad16(B));
+    GuideArgs g{};
+    g.mean = mean; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed; g.loss_scale = gd->loss_scale;
+    g.z = z; g.mean_out = mean_guided; g.x_out = x_next; g.grad_out = grad; g.scratch = w.guide;
+    g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
+    g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B;
+    HIPCK(h, launch_guide(h->dec, h->dyn, g, static_cast<hipStream_t>(stream)));
     return CLD_OK;
 }
 

@@ -160,4 +160,48 @@ struct ContextHeadArgs {
 };
 hipError_t launch_context_head(const ContextHeadArgs& a, hipStream_t s);
 
+// ---- sampling-time guidance (guide_kernels.hip; upstream diffuser.py:844-929, guidance_loss.py:219-254,2221-2282) ----
+struct GuideArgs {
+    const float* mean;          // [>=B,52,4] posterior mean of this step
+    const float* cond;          // [B,256]
+    const float* curr_states;   // [B,4]
+    const float* target_speed;  // [B,52]
+    const float* loss_scale;    // [B] or null: d(total loss)/d(sum_t |v_t - target_t|) per agent; null -> 1/52
+    const float* z;             // [B,52,4] N(0,1) draw or null (on-device generator)
+    float* mean_out;            // guided mean [B,52,4] or null
+    float* x_out;               // guided mean + sigma z, [>=B,52,4] or null
+    float* x_out2;              // second copy (the unconditional half in CFG mode) or null
+    float* grad_out;            // dL/dmean [B,52,4] or null (diagnostic / tests)
+    float* scratch;             // guide_scratch_floats(B) floats
+    float lr, perturb_th, sigma;
+    int optimizer;              // 0 = Adam (first step), 1 = SGD
+    int B;
+    unsigned long long seed, step_salt;
+};
+size_t guide_scratch_floats(int B);
+hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s);
+
+#ifdef __HIPCC__
+// counter-based N(0,1) for throughput runs without caller noise (splitmix64 -> Box-Muller); row = one (agent, step) float4
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float u01(unsigned long long bits) {
+    return ((float)(bits >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}
+typedef float rng_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rng_v4f normal4(unsigned long long seed, unsigned long long step_salt, unsigned row) {
+    const unsigned long long k = splitmix64(seed ^ splitmix64(step_salt * 0x100000000ull + row));
+    const unsigned long long r0 = splitmix64(k), r1 = splitmix64(k + 1), r2 = splitmix64(k + 2), r3 = splitmix64(k + 3);
+    const float m0 = sqrtf(-2.0f * logf(u01(r0))), m1 = sqrtf(-2.0f * logf(u01(r2)));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u01(r1), &s0, &c0);
+    sincosf(6.283185307179586f * u01(r3), &s1, &c1);
+    return rng_v4f{m0 * c0, m0 * s0, m1 * c1, m1 * s1};
+}
+#endif
+
 }  // namespace cld

@@ -107,14 +107,16 @@ class DmModel:
     # ---- dm_model.py:98-142 ------------------------------------------------------------
     @torch.no_grad()
     def forward(self, data_batch, aux_info, algo_config, noise: Optional[Mapping] = None, seed: int = 0,
-                class_free_guide_w: float = 0.0):
+                class_free_guide_w: float = 0.0, guidance: Optional[Mapping] = None):
         return self.sample_traj(data_batch, algo_config, aux_info, noise=noise, seed=seed,
-                                class_free_guide_w=class_free_guide_w)
+                                class_free_guide_w=class_free_guide_w, guidance=guidance)
 
     def sample_traj(self, data_batch, algo_config, aux_info, noise: Optional[Mapping] = None, seed: int = 0,
-                    class_free_guide_w: float = 0.0):
+                    class_free_guide_w: float = 0.0, guidance: Optional[Mapping] = None):
         """`class_free_guide_w` != 0 needs aux_info['non_cond_feat'] and follows the upstream CFG definition
-        (src/tbsim/models/diffuser.py:766-789; kwarg name as injected by policies/wrappers.py:143-167)."""
+        (src/tbsim/models/diffuser.py:766-789; kwarg name as injected by policies/wrappers.py:143-167).
+        `guidance` = dict(target_speed [B,52], loss_scale [B] | None, lr, perturb_th, optimizer): sampling-time guidance
+        of every step's posterior mean (upstream diffuser.py:844-929; Engine._guidance); curr_states come from aux_info."""
         batch_size = data_batch["history_positions"].size()[0]
         num_samp = int(cfg_get(algo_config, "num_samp", 1))
         BN = batch_size * num_samp
@@ -125,9 +127,15 @@ class DmModel:
             x_T = torch.randn(BN, 52, 4, device=self.device)
             z = torch.randn(self.n_timesteps, BN, 52, 4, device=self.device)
         x_T = torch.as_tensor(x_T).reshape(BN, 52, 4)
+        if guidance is not None:
+            guidance = dict(guidance)
+            guidance.setdefault("curr_states", aux_info["curr_states"])
+            for k in ("target_speed", "loss_scale"):
+                if guidance.get(k) is not None:
+                    guidance[k] = repeat_by_expand_at(torch.as_tensor(guidance[k]), num_samp, 0)
         x0, x1, logp = self.engine.sample(x_T, aux_info["cond_feat"], noise=z, seed=seed,
                                           non_cond=aux_info.get("non_cond_feat") if class_free_guide_w else None,
-                                          guidance_w=class_free_guide_w)
+                                          guidance_w=class_free_guide_w, guidance=guidance)
         return {"pred_traj": x0, "x1": x1, "log_prob_final": logp, "aux_info": aux_info}
 
     # ---- dm_model.py:144-163 -----------------------------------------------------------

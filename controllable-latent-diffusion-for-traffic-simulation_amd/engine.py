@@ -140,10 +140,45 @@ class Engine:
                                                C.byref(sigma), B, ws, wsn, self._stream()), "cld_ddpm_step")
         return xn, mean, float(sigma.value)
 
+    def _guidance(self, g: Mapping, B: int):
+        """dict(curr_states [B,4], target_speed [B,52], loss_scale [B] | None, lr | None, perturb_th | None | "sigma",
+        optimizer "adam" | "sgd") -> (CldGuidance, tensors kept alive).  lr None = sigma_t; perturb_th None = no clip (what
+        the reference's perturb() does), "sigma" = clip to sigma_t, a number = clip to it (include/cld.h)."""
+        cs = self._f32(g["curr_states"], (B, 4)); ts = self._f32(g["target_speed"], (B, T))
+        ls = None if g.get("loss_scale") is None else self._f32(g["loss_scale"], (B,))
+        th = g.get("perturb_th")
+        opt = g.get("optimizer", "adam")
+        if opt not in _lib.OPTIMIZERS:
+            raise CldError(f"unknown guidance optimizer '{opt}' (adam | sgd)")
+        cg = _lib.CldGuidance(cs.data_ptr(), ts.data_ptr(), None if ls is None else ls.data_ptr(),
+                              float(g["lr"]) if g.get("lr") else 0.0,
+                              -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt])
+        return cg, (cs, ts, ls)
+
+    def guidance_step(self, mean, cond, guidance: Mapping, sigma: float, z=None, want_grad=False):
+        """One guidance step on a posterior mean [B,52,4] (upstream PerturbationGuidance.perturb, guidance_loss.py:2221-2282)
+        -> guided mean (and x_next = guided + sigma z when z is given, dL/dmean when want_grad)."""
+        mean = self._f32(mean)
+        B = mean.shape[0]
+        mean = self._f32(mean, (B, T, D)); cond = self._f32(cond, (B, COND))
+        z = None if z is None else self._f32(z, (B, T, D))
+        cg, keep = self._guidance(guidance, B)
+        mg = torch.empty_like(mean)
+        xn = torch.empty_like(mean) if z is not None else None
+        gr = torch.empty_like(mean) if want_grad else None
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_guidance_step(self._h, _ptr(mean), _ptr(cond), C.byref(cg), C.c_float(sigma), _ptr(z),
+                                                   _ptr(mg), _ptr(xn), _ptr(gr), B, ws, wsn, self._stream()), "cld_guidance_step")
+        out = (mg,) + ((xn,) if z is not None else ()) + ((gr,) if want_grad else ())
+        return out[0] if len(out) == 1 else out
+
     def sample(self, x_T, cond, noise=None, seed: int = 0, want_x1=True, want_logp=True,
-               non_cond=None, guidance_w: float = 0.0):
+               non_cond=None, guidance_w: float = 0.0, guidance: Optional[Mapping] = None):
         """Full ancestral loop.  With `non_cond` [B,256] and guidance_w != 0: classifier-free guidance
-        (eps = (1+w) eps_cond - w eps_uncond, upstream diffuser.py:787), both passes as one 2B batch per step."""
+        (eps = (1+w) eps_cond - w eps_uncond, upstream diffuser.py:787), both passes as one 2B batch per step.
+        With `guidance` (see `_guidance`): the posterior mean of every step t > 0 takes one optimiser step on the
+        target-speed loss through decoder + roll-out before the noise is added (upstream diffuser.py:844-929)."""
         x_T = self._f32(x_T)
         B = x_T.shape[0]
         x_T = self._f32(x_T, (B, T, D)); cond = self._f32(cond, (B, COND))
@@ -154,7 +189,14 @@ class Engine:
         logp = torch.empty(B, dtype=torch.float32, device=self.device) if want_logp else None
         cfg = non_cond is not None and guidance_w != 0.0
         with torch.cuda.device(self.device):
-            if cfg:
+            if guidance is not None:
+                cg, keep = self._guidance(guidance, B)
+                non_cond = self._f32(non_cond, (B, COND)) if cfg else None
+                ws, wsn = self._workspace(2 * ((B + 15) // 16 * 16) if cfg else B)
+                self._check(self.lib.cld_sample_guided(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), _ptr(non_cond),
+                                                       C.c_float(guidance_w), C.byref(cg), n, _ptr(x0), _ptr(x1), _ptr(logp), B,
+                                                       C.c_uint64(seed), ws, wsn, self._stream()), "cld_sample_guided")
+            elif cfg:
                 non_cond = self._f32(non_cond, (B, COND))
                 ws, wsn = self._workspace(2 * ((B + 15) // 16 * 16))
                 self._check(self.lib.cld_sample_cfg(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), _ptr(non_cond),

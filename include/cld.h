@@ -138,6 +138,41 @@ int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const flo
                    float guidance_w, int32_t steps, float* x0, float* x1, float* logp, int32_t B, uint64_t seed,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Sampling-time guidance.  CLD's DmModel has none; the definition is the vendored upstream
+ * DiffuserModel.p_sample (src/tbsim/models/diffuser.py:844-929) with PerturbationGuidance.perturb
+ * (src/tbsim/utils/guidance_loss.py:2221-2282) and its `decoder` hook (:2259-2261) = LSTM decoder + unicycle roll-out:
+ * at every step t > 0 the posterior mean mu is decoded to a trajectory, the guidance loss
+ *     L = sum_agents loss_scale[b] * sum_t |v_t - target_speed[b,t]|         (TargetSpeedLoss, guidance_loss.py:219-254;
+ *         loss_scale[b] = weight / (agents guided in b's scene * 52) reproduces DiffuserGuidance.compute_guidance_loss :2143-2175)
+ * is differentiated through the roll-out and the decoder down to mu, ONE optimiser step is taken on mu
+ * (Adam's first step: delta = -lr * g / (|g| + 1e-8); SGD: delta = -lr * g; scene_edit_config.py:74-90 defaults adam,
+ * lr 0.3, grad_steps 1), and x_{t-1} = mu + delta + sigma_t z.  Step t = 0 is not guided (apply_guidance_output = False).
+ * Clipping: upstream means to clip delta to +-perturb_th (sigma_t when None, diffuser.py:893-897), but perturb() takes
+ * the delta between two names of the same tensor (x_guidance = x_initial, guidance_loss.py:2239,2275-2278), so its clip
+ * never changes anything.  perturb_th < 0 reproduces that behaviour (what the golden vectors recorded from the
+ * reference show); perturb_th = 0 clips to sigma_t and perturb_th > 0 to that value (the evident intent). */
+enum { CLD_GUIDE_ADAM = 0, CLD_GUIDE_SGD = 1 };
+typedef struct cld_guidance {
+    const float* curr_states;   /* [B,4]  (x, y, v, yaw) the roll-out starts from                        */
+    const float* target_speed;  /* [B,52] m/s                                                             */
+    const float* loss_scale;    /* [B] or NULL (= 1/52 per agent)                                         */
+    float lr;                   /* <= 0: sigma_t  (upstream: `if lr is None: lr = sigma`, diffuser.py:899) */
+    float perturb_th;           /* < 0: no clip (reference behaviour) ; 0: sigma_t ; > 0: that threshold    */
+    int32_t optimizer;          /* CLD_GUIDE_ADAM | CLD_GUIDE_SGD                                          */
+} cld_guidance;
+
+/* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */
+int cld_sample_guided(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
+                      float guidance_w, const cld_guidance* guidance, int32_t steps, float* x0, float* x1, float* logp,
+                      int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One guidance step on a given posterior mean [B,52,4] (teacher-forced form of the above, for tests and for callers that
+ * drive the loop themselves): mean_guided = mean + clip(delta); x_next = mean_guided + sigma * z; grad = dL/dmean.
+ * Outputs [B,52,4], any may be NULL. */
+int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const cld_guidance* guidance, float sigma,
+                      const float* z, float* mean_guided, float* x_next, float* grad, int32_t B,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* out = DmModel.log_prob(x_t, x_{t-1}, aux_info, t)  (dm_model.py:165-174):
  * mean over (T, D) of log N(x_{t-1}; mean(x_t, eps), sigma_t).  Forward only. */
 int cld_log_prob(cld_handle h, const float* x_t, const float* x_tm1, const float* cond, int32_t t_idx,

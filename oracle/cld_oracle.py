@@ -409,5 +409,53 @@ def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, tap
     return mlp_ln(w, CTX + "process_cond_mlp", torch.cat([sf, mf], dim=-1), 4)
 
 
+# --------------------------------------------------------------------------- #
+# f-3  sampling-time guidance (upstream diffuser.py:844-929, guidance_loss.py:219-254,2221-2282)
+# --------------------------------------------------------------------------- #
+def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor, loss_scale: Optional[Tensor],
+                  lr: float, perturb_th: Optional[float], optimizer: str = "adam"):
+    """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282, grad_steps = 1) with decoder = `decode` and
+    TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target|; Adam's first step is
+    -lr * g / (|g| + 1e-8) (bias-corrected moments of a single gradient), SGD's -lr * g.  perturb_th None = the
+    reference's actual behaviour: its clip (:2275-2278) acts on x_guidance - x_initial, two names of one tensor
+    (:2239), so it never changes anything (the golden vectors confirm); a number clips the step as the code intends.
+    Returns (guided mean, gradient)."""
+    x = mean.clone().requires_grad_(True)
+    with torch.enable_grad():
+        traj = decode(wdec, x, cond, cs, True)
+        dev = (traj[..., 2] - target_speed).abs()
+        sc = loss_scale if loss_scale is not None else torch.full((mean.shape[0],), 1.0 / mean.shape[1], dtype=mean.dtype)
+        loss = (dev.sum(dim=1) * sc).sum()
+        (g,) = torch.autograd.grad(loss, x)
+    delta = -lr * g / (g.abs() + 1e-8) if optimizer == "adam" else -lr * g
+    if perturb_th is not None:
+        delta = delta.clamp(-perturb_th, perturb_th)
+    return mean + delta, g
+
+
+def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor,
+                  loss_scale: Optional[Tensor] = None, lr: Optional[float] = 0.3, optimizer: str = "adam",
+                  non_cond: Optional[Tensor] = None, guidance_w: float = 0.0, clip_to_sigma: bool = False) -> dict:
+    """The ancestral loop of dm_model.py:119-132 with upstream's p_sample guidance (diffuser.py:844-929): steps t > 0
+    perturb the posterior mean before the noise is added (lr None -> sigma_t); t = 0 is unguided."""
+    n = sched["betas"].shape[0]
+    x = x_T
+    x1 = None
+    for s_, i in enumerate(reversed(range(n))):
+        t = torch.full((x.shape[0],), i, dtype=torch.long)
+        eps = unet_forward(w, x, cond, t)
+        if non_cond is not None:
+            eps = (1 + guidance_w) * eps - guidance_w * unet_forward(w, x, non_cond, t)
+        mean = sched["x_t_cof"][i] * x - sched["noise_cof"][i] * eps
+        sigma = float((0.5 * sched["posterior_log_variance_clipped"][i]).exp())
+        if i > 0:
+            mean, _ = guidance_step(wdec, mean, cond, cs, target_speed, loss_scale, sigma if lr is None else lr,
+                                    sigma if clip_to_sigma else None, optimizer)
+        x = mean + (0.0 if i == 0 else sigma) * noise[s_]
+        if i == 1:
+            x1 = x.clone()
+    return {"pred_traj": x, "x1": x1}
+
+
 def to_torch(d: dict, dtype=torch.float32) -> Dict[str, Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in d.items()}

@@ -180,6 +180,36 @@ def section_context(ref):
          curr_states=out["curr_states"], state_feat=state_feat, map_feat=map_feat, cond_feat=out["cond_feat"])
 
 
+def section_guidance(ref):
+    """Guidance row.  The reference's own PerturbationGuidance.perturb + DiffuserGuidance + TargetSpeedLoss
+    (src/tbsim/utils/guidance_loss.py:2221-2282,2106-2175,219-254) run unmodified -- optimiser step, clipping, per-scene
+    loss averaging -- with the `decoder` hook (:2259-2261) set to the oracle's decode (itself pinned by decode.npz to the
+    reference's lstm_dec + convert_action_to_state_and_action).  Two scenes of 3 and 5 agents; Adam and SGD."""
+    import tbsim.utils.guidance_loss as gl
+    from oracle import cld_oracle as O
+    B, T_ = 8, 52
+    wdec = O.to_torch(synth.make_decoder_weights(W_SEED))
+    inp = synth.make_inputs(B, IN_SEED)
+    cond, cs = T(inp["cond_feat"]), T(inp["curr_states"])
+    mean = T(synth.normal(IN_SEED, "guide_mean", (B, T_, 4)))
+    tgt = synth.uniform(IN_SEED, "guide_target_speed", (B, T_), 0.0, 12.0)
+    scene_index = torch.tensor([0, 0, 0, 1, 1, 1, 1, 1])
+    cfgs = [[{"name": "target_speed", "weight": 1.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None}],
+            [{"name": "target_speed", "weight": 2.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None}]]
+    out = {}
+    for opt_name, lr, th in (("adam", 0.3, 0.2), ("sgd", 5.0, 0.5)):
+        pg = gl.PerturbationGuidance(transform=lambda x, data_batch, params, bsize, num_samp: x, transform_params=None)
+        pg.set_guidance(cfgs)
+        x_init = mean.clone()
+        xg, _ = pg.perturb(x_init, {"scene_index": scene_index}, {"optimizer": opt_name, "lr": lr, "grad_steps": 1, "perturb_th": th},
+                           num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
+        out[f"guided_{opt_name}"] = xg.detach()
+    save("guidance", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "mean": "normal(in_seed,'guide_mean')",
+                      "target_speed": "uniform(in_seed,'guide_target_speed',0,12)", "scenes": [3, 5], "weights": [1.0, 2.0],
+                      "adam": {"lr": 0.3, "perturb_th": 0.2}, "sgd": {"lr": 5.0, "perturb_th": 0.5},
+                      "decoder": "oracle.decode (pinned by decode.npz)"}, **out)
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -187,11 +217,12 @@ def main():
     algo = ref.algo
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
-            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context}[name](ref)
+            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
     section_context(ref)
+    section_guidance(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

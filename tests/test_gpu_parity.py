@@ -263,3 +263,68 @@ def test_context_encoder_agents_are_independent(eng_ctx):
     idx = torch.arange(261, device="cuda") % 3
     big = eng_ctx.context_encode(img3[idx], cs3[idx])
     assert torch.equal(big, c3[idx])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# f-3  sampling-time guidance (upstream diffuser.py:844-929, guidance_loss.py:219-254,2221-2282)
+# ---------------------------------------------------------------------------------------------------------
+def _guidance_inputs(meta):
+    B = meta["B"]
+    inp = synth.make_inputs(B, meta["in_seed"])
+    scale = np.concatenate([np.full(n, w / (n * 52), np.float32) for n, w in zip(meta["scenes"], meta["weights"])])
+    return (torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"]),
+            torch.from_numpy(synth.normal(meta["in_seed"], "guide_mean", (B, 52, 4))),
+            torch.from_numpy(synth.uniform(meta["in_seed"], "guide_target_speed", (B, 52), 0.0, 12.0)), torch.from_numpy(scale))
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_guidance_step_golden(golden, eng_jitter, opt):
+    """cld_guidance_step against the reference's own perturb() (golden 'guidance').  SGD compares the raw gradient path
+    (step = lr * g, |g| ~ 1e-3): 1e-5 relative.  Adam normalises the step to +-lr wherever |g| >> 1e-8: 1e-3 abs."""
+    from oracle import cld_oracle as O
+    meta, g = golden("guidance")
+    cond, cs, mean, tgt, scale = _guidance_inputs(meta)
+    gd = {"curr_states": cs, "target_speed": tgt, "loss_scale": scale, "lr": meta[opt]["lr"], "perturb_th": None, "optimizer": opt}
+    mg, grad = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+    _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, tgt, scale, meta[opt]["lr"], None, opt)
+    assert (grad.cpu() - gref).abs().max().item() <= 2e-5 * gref.abs().max().item()
+    step = np.abs(g[f"guided_{opt}"] - mean.numpy()).max()
+    assert np.abs(mg.cpu().numpy() - g[f"guided_{opt}"]).max() <= (1e-3 if opt == "adam" else max(2e-5 * step, 2.5e-7))   # 2.5e-7: one ulp of the O(1) means
+    # the clip variants the reference intends but never applies: sigma_t and an explicit threshold
+    for th, bound in (("sigma", 0.5), (0.1, 0.1)):
+        gd2 = dict(gd, perturb_th=th)
+        mg2 = eng_jitter.guidance_step(mean, cond, gd2, sigma=0.5)
+        ref2, _ = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, tgt, scale, meta[opt]["lr"], bound, opt)
+        assert (mg2.cpu() - ref2).abs().max().item() <= 1e-3
+        assert (mg2.cpu() - mean).abs().max().item() <= bound + 1e-6
+
+
+@pytest.fixture(scope="module")
+def eng10():
+    return _engine(10, True)
+
+
+def test_guided_chain_vs_oracle(eng10):
+    """10-step guided chain (Adam, lr 0.3, the upstream defaults) against the oracle's autograd restatement, plain and with
+    CFG; guidance with zero loss weight must reproduce the unguided chain bit for bit."""
+    from oracle import cld_oracle as O
+    B, n = 6, 10
+    w, wd = O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), O.to_torch(synth.make_decoder_weights(0))
+    inp = synth.make_inputs(B, 3)
+    nz = synth.make_noise(B, n, 5)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    tgt = torch.from_numpy(synth.uniform(3, "tgt", (B, 52), 0.0, 12.0))
+    non_cond = torch.from_numpy(synth.normal(3, "non_cond_feat", (B, 256)))
+    x_T, z = torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"])
+    gd = {"curr_states": cs, "target_speed": tgt, "lr": 0.3, "optimizer": "adam"}
+    for cfg_w, nc in ((0.0, None), (2.0, non_cond)):
+        x0, x1, _ = eng10.sample(x_T, cond, noise=z, non_cond=nc, guidance_w=cfg_w, guidance=gd)
+        ref = O.sample_guided(w, wd, O.schedule(n), x_T, z, cond, cs, tgt, None, 0.3, "adam", nc, cfg_w)
+        scale = max(1.0, float(ref["pred_traj"].abs().max()))
+        # Adam's sign-like step can flip where |g| ~ 1e-8 between two fp32 implementations: allow a handful of elements
+        d = (x0.cpu() - ref["pred_traj"]).abs() / scale
+        assert float((d > 1e-3).float().mean()) <= 0.01, float(d.max())
+    plain, _, _ = eng10.sample(x_T, cond, noise=z)
+    zero = dict(gd, loss_scale=torch.zeros(B))
+    g0, _, _ = eng10.sample(x_T, cond, noise=z, guidance=zero)
+    assert torch.equal(plain, g0)

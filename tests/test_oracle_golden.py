@@ -181,3 +181,27 @@ def test_context_encoder_around_the_resnet(golden):
     scale = float(np.abs(g["map_feat"]).max())
     assert np.abs(taps["map_feat"].numpy() - g["map_feat"]).max() <= 1e-5 * scale      # thread-count spread of torch's conv2d
     assert np.abs(full.numpy() - g["cond_feat"]).max() <= 2e-5
+
+
+def _guidance_inputs(meta):
+    B = meta["B"]
+    inp = synth.make_inputs(B, meta["in_seed"])
+    sizes, weights = meta["scenes"], meta["weights"]
+    scale = np.concatenate([np.full(n, w / (n * 52), np.float32) for n, w in zip(sizes, weights)])   # DiffuserGuidance: per-scene mean x weight
+    return (torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"]),
+            torch.from_numpy(synth.normal(meta["in_seed"], "guide_mean", (B, 52, 4))),
+            torch.from_numpy(synth.uniform(meta["in_seed"], "guide_target_speed", (B, 52), 0.0, 12.0)), torch.from_numpy(scale))
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_guidance_step_vs_reference_perturb(golden, opt):
+    """f-3: the reference's own PerturbationGuidance.perturb / DiffuserGuidance / TargetSpeedLoss with the oracle's decode as
+    the decoder hook (make_golden.section_guidance).  The fixture was recorded with perturb_th = 0.2 / 0.5: upstream's clip is
+    a no-op (it clips the delta between two names of one tensor), which is what perturb_th=None restates."""
+    meta, g = golden("guidance")
+    cond, cs, mean, tgt, scale = _guidance_inputs(meta)
+    wdec = O.to_torch(synth.make_decoder_weights(meta["w_seed"]))
+    xg, grad = O.guidance_step(wdec, mean, cond, cs, tgt, scale, meta[opt]["lr"], None, opt)
+    assert np.abs(xg.numpy() - g[f"guided_{opt}"]).max() <= 2e-6
+    if opt == "adam":     # the recorded step exceeds the 0.2 threshold it was "clipped" to
+        assert np.abs(g["guided_adam"] - mean.numpy()).max() > 0.29
