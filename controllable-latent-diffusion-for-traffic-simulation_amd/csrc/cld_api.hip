@@ -1094,6 +1094,22 @@ int cld_context_encode(cld_handle h, const float* image, const float* curr_state
     return CLD_OK;
 }
 
+int cld_compute_reward(cld_handle h, const float* traj, const float* traj_scaled, const float* raster_from_agent,
+                       const uint8_t* drivable_map, int32_t H, int32_t W, const float* other_pos, const uint8_t* other_avail,
+                       int32_t S, int32_t T_other, float collision_thresh, float* reward, float* offroad, float* collision,
+                       int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!traj || !raster_from_agent || !drivable_map || B < 1 || H < 1 || W < 1 || S < 0 || T_other < 0 ||
+        (S > 0 && T_other > 0 && (!other_pos || !other_avail)) || (!reward && !offroad && !collision))
+        return fail(h, CLD_ERR_ARG, "cld_compute_reward: bad argument");
+    RewardArgs a{};
+    a.traj = traj; a.traj_scaled = traj_scaled; a.raster_from_agent = raster_from_agent; a.drivable_map = drivable_map;
+    a.other_pos = other_pos; a.other_avail = other_avail; a.reward = reward; a.offroad = offroad; a.collision = collision;
+    a.collision_thresh = collision_thresh; a.B = B; a.H = H; a.W = W; a.S = S; a.To = T_other < T ? T_other : T;
+    HIPCK(h, launch_reward(a, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
 int cld_world_step(cld_handle h, const float* traj, const float* centroid, const float* yaw, int32_t k, float* world,
                    float* next_curr_states, int32_t B, void* stream) {
     if (!h) return CLD_ERR_ARG;

@@ -181,6 +181,20 @@ struct GuideArgs {
 size_t guide_scratch_floats(int B);
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s);
 
+// PPO reward (models/rl/criticmodel.py:7-64)
+struct RewardArgs {
+    const float* traj;                // [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate), agent frame
+    const float* traj_scaled;         // [B,52,6] scaled (jerk term) or null
+    const float* raster_from_agent;   // [B,3,3]
+    const unsigned char* drivable_map;   // [B,H,W] bool
+    const float* other_pos;           // [B,S,To,2]
+    const unsigned char* other_avail; // [B,S,To] bool
+    float* reward; float* offroad; float* collision;   // [B] each, any may be null
+    float collision_thresh;
+    int B, H, W, S, To;
+};
+hipError_t launch_reward(const RewardArgs& a, hipStream_t s);
+
 #ifdef __HIPCC__
 // counter-based N(0,1) for throughput runs without caller noise (splitmix64 -> Box-Muller); row = one (agent, step) float4
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {

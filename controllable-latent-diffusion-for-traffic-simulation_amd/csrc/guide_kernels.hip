@@ -240,3 +240,54 @@ hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const Guide
 }
 
 }  // namespace cld
+
+// =============================================================================================
+// PPO reward of the reference (models/rl/criticmodel.py:7-64,88-145), one wave per agent, lane t = timestep t:
+//   offroad   : trajectory point -> raster pixel (transform_points_tensor :101-112: p' = R[:2,:2] p + R[:2,2]), round half
+//               to even (torch.round), clamp to the map, -1 per timestep on a non-drivable pixel              (:13-29)
+//   collision : -1 per (other agent, timestep < T_other) closer than the threshold and available              (:42-64)
+//   jerk      : 0.1 * mean_t |acc_{t+1} - acc_t| / dt on the SCALED acceleration channel                      (:33-37)
+// =============================================================================================
+namespace cld {
+
+__global__ __launch_bounds__(64) void reward_kernel(const RewardArgs a) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    float off = 0.f, col = 0.f, jerk = 0.f;
+    if (t < 52) {
+        const float* p = a.traj + ((size_t)b * 52 + t) * 6;
+        const float x = p[0], y = p[1];
+        const float* R = a.raster_from_agent + (size_t)b * 9;
+        const float rx = x * R[0] + y * R[1] + R[2];          // bmm(points, R^T[:2,:2]) + R^T[2,:2]
+        const float ry = x * R[3] + y * R[4] + R[5];
+        long cx = (long)rintf(rx), cy = (long)rintf(ry);
+        cx = cx < 0 ? 0 : (cx > a.W - 1 ? a.W - 1 : cx);
+        cy = cy < 0 ? 0 : (cy > a.H - 1 ? a.H - 1 : cy);
+        off = a.drivable_map[((size_t)b * a.H + cy) * a.W + cx] ? 0.f : -1.f;
+        if (t < a.To) {
+            for (int s = 0; s < a.S; ++s) {
+                const size_t o = ((size_t)b * a.S + s) * a.To + t;
+                const float dx = x - a.other_pos[2 * o], dy = y - a.other_pos[2 * o + 1];
+                if (sqrtf(dx * dx + dy * dy) < a.collision_thresh && a.other_avail[o]) col -= 1.f;
+            }
+        }
+        if (t < 51 && a.traj_scaled) {
+            const float* q = a.traj_scaled + ((size_t)b * 52 + t) * 6;
+            jerk = fabsf((q[6 + 4] - q[4]) / 0.1f);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { off += __shfl_xor(off, o); col += __shfl_xor(col, o); jerk += __shfl_xor(jerk, o); }
+    if (t == 0) {
+        const float jp = jerk * (1.0f / 51.0f);
+        if (a.offroad) a.offroad[b] = off;
+        if (a.collision) a.collision[b] = col;
+        if (a.reward) a.reward[b] = off + col - jp * 0.1f;
+    }
+}
+
+hipError_t launch_reward(const RewardArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(reward_kernel, dim3(a.B), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cld

@@ -290,6 +290,29 @@ class Engine:
                                                     self._stream()), "cld_context_encode")
         return (cond, mf) if want_map_feat else cond
 
+    def compute_reward(self, traj, traj_scaled, raster_from_agent, drivable_map, other_pos=None, other_avail=None,
+                       collision_thresh: float = 0.8):
+        """models/rl/criticmodel.py:7-64 per agent -> (reward, offroad, collision), each [B]."""
+        traj = self._f32(traj)
+        B = traj.shape[0]
+        traj = self._f32(traj, (B, T, 6))
+        ts = None if traj_scaled is None else self._f32(traj_scaled, (B, T, 6))
+        R = self._f32(raster_from_agent, (B, 3, 3))
+        dm = torch.as_tensor(drivable_map).to(self.device).ne(0).to(torch.uint8).contiguous()
+        H, W = int(dm.shape[-2]), int(dm.shape[-1])
+        S = To = 0
+        op = oa = None
+        if other_pos is not None and torch.as_tensor(other_pos).numel() > 0:
+            op = self._f32(other_pos)
+            S, To = int(op.shape[1]), int(op.shape[2])
+            oa = torch.as_tensor(other_avail).to(self.device).ne(0).to(torch.uint8).contiguous()
+        r, o, c = (torch.empty(B, dtype=torch.float32, device=self.device) for _ in range(3))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_compute_reward(self._h, _ptr(traj), _ptr(ts), _ptr(R), _ptr(dm), H, W, _ptr(op), _ptr(oa), S, To,
+                                                    C.c_float(collision_thresh), _ptr(r), _ptr(o), _ptr(c), B, self._stream()),
+                        "cld_compute_reward")
+        return r, o, c
+
     def world_step(self, traj, centroid, yaw, k: int):
         """env_trajdata.py:452-468 for plan step k -> (world [B,3] = (x, y, h), next curr_states [B,4])."""
         traj = self._f32(traj)

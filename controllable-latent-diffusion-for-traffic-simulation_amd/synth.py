@@ -365,3 +365,29 @@ def make_raster(B: int, seed: int = 1, dense: bool = False) -> np.ndarray:
     sem = np.repeat(np.repeat(coarse, 16, axis=2), 16, axis=3)
     img[:, 31:34] = (sem > 0.5).astype(np.float32)
     return img
+
+
+def make_reward_inputs(B: int, seed: int = 1, S: int = 5, T_other: int = 52) -> dict:
+    """Synthetic PPO-reward inputs (models/rl/criticmodel.py:7-64): a smooth trajectory [B,52,6] in the agent frame (scaled copy
+    via the config's mean / std), raster_from_agent = 2 px/m with the ego at (56, 112) and a small per-agent rotation
+    (trajdata_utils.py:380-389), a blobby drivable map, and `S` other agents that shadow the trajectory at random offsets so
+    that some pairs fall inside the 0.8 m collision radius."""
+    fut = make_future(B, seed)
+    pos, yaw = fut["target_positions"].astype(np.float64), fut["target_yaws"].astype(np.float64)
+    v = np.linalg.norm(np.diff(np.concatenate([np.zeros((B, 1, 2)), pos], axis=1), axis=1), axis=-1) / 0.1
+    acc = np.diff(np.concatenate([fut["curr_speed"].astype(np.float64)[:, None], v], axis=1), axis=1) / 0.1
+    yr = np.diff(np.concatenate([np.zeros((B, 1)), yaw[..., 0]], axis=1), axis=1) / 0.1
+    traj = np.concatenate([pos, v[..., None], yaw, acc[..., None], yr[..., None]], axis=-1).astype(np.float32)
+    mean = np.array([13.162, -0.13891, 5.0223, -0.0046415, -0.0080072, -0.0013546], np.float32)
+    std = np.array([13.0717, 2.2462, 3.6187, 0.2210, 2.5770, 0.0840], np.float32)
+    th = uniform(seed, "reward_rot", (B,), -0.3, 0.3).astype(np.float64)
+    R = np.zeros((B, 3, 3), np.float64)
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1] = 2 * np.cos(th), -2 * np.sin(th), 2 * np.sin(th), 2 * np.cos(th)
+    R[:, 0, 2], R[:, 1, 2], R[:, 2, 2] = 56.0, 112.0, 1.0
+    coarse = uniform(seed, "reward_map", (B, 28, 28), 0.0, 1.0)
+    dmap = np.repeat(np.repeat(coarse, 8, axis=1), 8, axis=2) > 0.02
+    off = normal(seed, "reward_other_off", (B, S, 1, 2)) * 1.5 + normal(seed, "reward_other_jit", (B, S, T_other, 2)) * 0.5
+    other = pos[:, None, :T_other].astype(np.float32) + off
+    avail = uniform(seed, "reward_avail", (B, S, T_other), 0.0, 1.0) > 0.3
+    return {"traj": traj, "traj_scaled": (traj - mean) / std, "raster_from_agent": R.astype(np.float32), "drivable_map": dmap,
+            "other_pos": other.astype(np.float32), "other_avail": avail}

@@ -221,6 +221,20 @@ size_t cld_context_workspace_bytes(cld_handle h, int32_t B);
 int cld_context_encode(cld_handle h, const float* image, const float* curr_states, float* cond_feat, float* map_feat,
                        int32_t B, void* workspace, size_t workspace_bytes, void* stream);
 
+/* PPO reward of the reference (models/rl/criticmodel.py:7-64), per agent:
+ *   offroad   = -#timesteps whose position, mapped to the raster with raster_from_agent (transform_points_tensor, :88-112),
+ *               rounded (half to even) and clamped, falls on a non-drivable pixel of drivable_map                  (:13-29)
+ *   collision = -#(other agent, timestep < T_other) within collision_thresh (0.8 m) and available                  (:42-64)
+ *   reward    = offroad + collision - 0.1 * mean_t |acc_{t+1} - acc_t| / 0.1 on traj_scaled[..., 4]                (:33-38)
+ * traj [B,52,6] descaled, traj_scaled [B,52,6] (NULL: no jerk term), raster_from_agent [B,3,3], drivable_map [B,H,W] bytes
+ * (non-zero = drivable), other_pos [B,S,T_other,2], other_avail [B,S,T_other] bytes; outputs [B], any may be NULL.
+ * (The reference's compute_reward unpacks a 4-D trajectory and then calls 3-D-only helpers, so it cannot run as written;
+ * this is the per-agent quantity its helpers define, num_samp = 1.) */
+int cld_compute_reward(cld_handle h, const float* traj, const float* traj_scaled, const float* raster_from_agent,
+                       const uint8_t* drivable_map, int32_t H, int32_t W, const float* other_pos, const uint8_t* other_avail,
+                       int32_t S, int32_t T_other, float collision_thresh, float* reward, float* offroad, float* collision,
+                       int32_t B, void* stream);
+
 /* Closed-loop kinematic update of EnvUnifiedSimulation._step (src/tbsim/envs/env_trajdata.py:452-468) for plan step k
  * (the last of the n_step_action executed steps): traj [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate) in the agent frame
  * at planning time, centroid [B,2], yaw [B] (world pose at planning time) -> world [B,3] = (x, y, h) with

@@ -457,5 +457,42 @@ def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: 
     return {"pred_traj": x, "x1": x1}
 
 
+# --------------------------------------------------------------------------- #
+# f-3  PPO reward (models/rl/criticmodel.py:7-64,88-145)
+# --------------------------------------------------------------------------- #
+def transform_points(traj_xy: Tensor, raster_from_agent: Tensor) -> Tensor:
+    """criticmodel.py:101-112 -- [B,T,2] points times the transposed 3x3: p' = R[:2,:2] p + R[:2,2]."""
+    Tm = raster_from_agent.transpose(1, 2)
+    return torch.bmm(traj_xy, Tm[:, :2, :2]) + Tm[:, -1:, :2]
+
+
+def offroad_flags(traj: Tensor, raster_from_agent: Tensor, drivable_map: Tensor) -> Tensor:
+    """criticmodel.py:13-23 / :121-127 -- [B,T] True where the rounded, clamped raster pixel is drivable."""
+    B, T = traj.shape[:2]
+    ti = transform_points(traj[..., :2], raster_from_agent).round().long()
+    cols = ti[..., 0].clamp(0, drivable_map.shape[-1] - 1)
+    rows = ti[..., 1].clamp(0, drivable_map.shape[-2] - 1)
+    bi = torch.arange(B).view(B, 1).expand(B, T)
+    return drivable_map[bi, rows, cols] != 0
+
+
+def collision_reward(traj_xy: Tensor, other_pos: Tensor, other_avail: Tensor, thresh: float = 0.8) -> Tensor:
+    """criticmodel.py:42-64 (3-D branch) -- minus the number of (other agent, timestep) pairs closer than `thresh`."""
+    To = other_pos.shape[2]
+    d = (traj_xy[:, None, :To] - other_pos).norm(dim=-1)
+    return -((d < thresh) & (other_avail != 0)).float().sum(dim=(1, 2))
+
+
+def compute_reward(traj: Tensor, traj_scaled: Tensor, raster_from_agent: Tensor, drivable_map: Tensor, other_pos: Tensor,
+                   other_avail: Tensor, thresh: float = 0.8):
+    """criticmodel.py:7-40 per agent (num_samp = 1; the reference function itself cannot run: it unpacks 4-D and calls the
+    3-D helpers) -> (reward, offroad, collision)."""
+    off = -(~offroad_flags(traj, raster_from_agent, drivable_map)).float().sum(dim=-1)
+    col = collision_reward(traj[..., :2], other_pos, other_avail, thresh)
+    acc = traj_scaled[..., 4]
+    jerk = ((acc[:, 1:] - acc[:, :-1]) / 0.1).abs().mean(dim=-1)
+    return off + col - jerk * 0.1, off, col
+
+
 def to_torch(d: dict, dtype=torch.float32) -> Dict[str, Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in d.items()}

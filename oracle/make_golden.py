@@ -210,6 +210,28 @@ def section_guidance(ref):
                       "decoder": "oracle.decode (pinned by decode.npz)"}, **out)
 
 
+def section_reward(ref):
+    """PPO-reward row: the reference's transform_points_tensor, compute_collision_reward (3-D branch) and
+    failure_rate_compute (models/rl/criticmodel.py:42-64,88-145) on synthetic inputs.  compute_reward itself cannot run
+    (it unpacks a 4-D trajectory, then calls the 3-D helpers); its offroad term is pinned through failure_rate_compute's
+    per-agent any-offroad flag (called once per agent) and its collision term through compute_collision_reward."""
+    import models.rl.criticmodel as cm
+    B = 16
+    ri = synth.make_reward_inputs(B, IN_SEED)
+    traj, R, dm = T(ri["traj"]), T(ri["raster_from_agent"]), T(ri["drivable_map"])
+    batch = {"raster_from_agent": R, "drivable_map": dm, "all_other_agents_future_positions": T(ri["other_pos"]),
+             "all_other_agents_future_availability": T(ri["other_avail"])}
+    pts = cm.transform_points_tensor(traj[..., :2], R)
+    col = cm.compute_collision_reward(traj[..., :2], batch)[:, 0]
+    rates = cm.failure_rate_compute(traj, batch)
+    any_off = []
+    for b in range(B):      # per-agent offroad flag: failure_rate_compute on a one-agent batch
+        one = {k: v[b:b + 1] for k, v in batch.items()}
+        any_off.append(cm.failure_rate_compute(traj[b:b + 1], one)["offroad_failure_rate"])
+    save("reward", {"B": B, "in_seed": IN_SEED, "inputs": "synth.make_reward_inputs(B, in_seed)", "rates": rates},
+         raster_points=pts, collision_reward=col, any_offroad=np.array(any_off, np.float32))
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -217,12 +239,13 @@ def main():
     algo = ref.algo
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
-            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance}[name](ref)
+            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
     section_context(ref)
     section_guidance(ref)
+    section_reward(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

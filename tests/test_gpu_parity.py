@@ -328,3 +328,22 @@ def test_guided_chain_vs_oracle(eng10):
     zero = dict(gd, loss_scale=torch.zeros(B))
     g0, _, _ = eng10.sample(x_T, cond, noise=z, guidance=zero)
     assert torch.equal(plain, g0)
+
+
+def test_reward_golden_and_oracle(golden, eng_jitter):
+    """cld_compute_reward: collision counts and offroad flags bit-exact against the reference's helpers (golden 'reward'),
+    counts / jerk term against the oracle."""
+    from oracle import cld_oracle as O
+    meta, g = golden("reward")
+    ri = {k: torch.from_numpy(v) for k, v in synth.make_reward_inputs(meta["B"], meta["in_seed"]).items()}
+    r, off, col = eng_jitter.compute_reward(ri["traj"], ri["traj_scaled"], ri["raster_from_agent"], ri["drivable_map"],
+                                            ri["other_pos"], ri["other_avail"])
+    assert np.array_equal(col.cpu().numpy(), g["collision_reward"])
+    assert np.array_equal((off.cpu() < 0).float().numpy(), g["any_offroad"])
+    rr, ro, rc = O.compute_reward(ri["traj"], ri["traj_scaled"], ri["raster_from_agent"], ri["drivable_map"], ri["other_pos"],
+                                  ri["other_avail"])
+    assert torch.equal(off.cpu(), ro) and torch.equal(col.cpu(), rc)
+    assert (r.cpu() - rr).abs().max().item() <= 1e-5 * max(1.0, rr.abs().max().item())
+    # no other agents: collision term vanishes
+    r2, _, c2 = eng_jitter.compute_reward(ri["traj"], ri["traj_scaled"], ri["raster_from_agent"], ri["drivable_map"])
+    assert float(c2.abs().max()) == 0.0

@@ -205,3 +205,17 @@ def test_guidance_step_vs_reference_perturb(golden, opt):
     assert np.abs(xg.numpy() - g[f"guided_{opt}"]).max() <= 2e-6
     if opt == "adam":     # the recorded step exceeds the 0.2 threshold it was "clipped" to
         assert np.abs(g["guided_adam"] - mean.numpy()).max() > 0.29
+
+
+def test_reward_helpers_vs_reference(golden):
+    """f-3: raster transform, collision count and per-agent offroad flag against the reference's criticmodel helpers
+    (its compute_reward cannot run as written; see make_golden.section_reward)."""
+    meta, g = golden("reward")
+    ri = {k: torch.from_numpy(v) for k, v in synth.make_reward_inputs(meta["B"], meta["in_seed"]).items()}
+    assert np.abs(O.transform_points(ri["traj"][..., :2], ri["raster_from_agent"]).numpy() - g["raster_points"]).max() == 0.0
+    r, off, col = O.compute_reward(ri["traj"], ri["traj_scaled"], ri["raster_from_agent"], ri["drivable_map"], ri["other_pos"],
+                                   ri["other_avail"])
+    assert np.array_equal(col.numpy(), g["collision_reward"])
+    assert np.array_equal((off < 0).float().numpy(), g["any_offroad"])
+    assert abs(float((off < 0).float().mean()) - meta["rates"]["offroad_failure_rate"]) < 1e-6
+    assert abs(float((col < 0).float().mean()) - meta["rates"]["collision_failure_rate"]) < 1e-6
