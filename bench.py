@@ -48,6 +48,9 @@ def main():
                          "e.g. --closed-loop 20 --denoise-steps 50 --scenes 64 --agents 64")
     ap.add_argument("--precision", choices=["f32", "f16x2"], default="f32",
                     help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split operands with fp32 accumulation (include/cld.h)")
+    ap.add_argument("--guide", action="store_true",
+                    help="sampling-time guidance on every step t > 0 (target-speed loss through decoder + roll-out, Adam lr 0.3; "
+                         "BASELINE configs[2]: --agents 64 --cfg-w 2.0 --guide)")
     ap.add_argument("--no-context", action="store_true",
                     help="skip the ContextEncoder (producer of cond_feat, SURVEY 8(f-1)) measurement / closed-loop stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -103,6 +106,10 @@ def main():
     gathered = torch.empty(world * B, 52, 6, device=dev) if distributed else None
 
     world0 = torch.zeros(B, 3, device=dev)
+    guidance = None
+    if args.guide:        # upstream defaults: adam, lr 0.3, one gradient step per denoising step (scene_edit_config.py:74-90)
+        guidance = {"curr_states": cs, "target_speed": torch.rand(B, 52, device=dev, generator=g) * 12.0,
+                    "loss_scale": torch.full((B,), 1.0 / (args.agents * 52), device=dev), "lr": 0.3, "optimizer": "adam"}
 
     use_ctx = not args.no_context
     if use_ctx:
@@ -125,13 +132,13 @@ def main():
             for _ in range(args.closed_loop):
                 cnd = eng.context_encode(raster, c) if use_ctx else cond      # obs -> cond_feat (context_utils.py:40-61)
                 x0, _, _ = eng.sample(x_T, cnd, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w,
-                                      want_x1=False, want_logp=False)
+                                      want_x1=False, want_logp=False, guidance=None if guidance is None else dict(guidance, curr_states=c))
                 traj = eng.decode(x0, cnd, c, descaled_output=True)
                 if distributed:
                     gather_trajectories(traj, gathered)
                 world, c = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), 4)
             return traj
-        x0, x1, logp = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w)
+        x0, x1, logp = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w, guidance=guidance)
         traj = eng.decode(x0, cond, cs, descaled_output=True)
         if distributed:
             gather_trajectories(traj, gathered)
@@ -184,11 +191,12 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f16x2 (fp16 hi+lo operand split, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]" if (args.scenes, args.agents, args.cfg_w, args.closed_loop) == (32, 32, 0.0, 0) else "custom")
+        "config": {"workload": ("BASELINE configs[1]" if (args.scenes, args.agents, args.cfg_w, args.closed_loop, args.guide) == (32, 32, 0.0, 0, False) else "custom")
                                + (f" closed loop, {args.closed_loop} sim steps per bench step, each" if args.closed_loop else "")
                                + f": {args.scenes} scenes x {args.agents} agents per GPU, {n} denoising steps "
                                "(DDPM ancestral loop of the reference), latent seq 52 x 4, cond 256, "
-                               + (f"CFG w={args.cfg_w} (2 U-Net passes per step)" if args.cfg_w else "CFG off") + "; "
+                               + (f"CFG w={args.cfg_w} (2 U-Net passes per step)" if args.cfg_w else "CFG off")
+                               + ("; target-speed guidance gradient every step" if args.guide else "") + "; "
                                "+ LSTM decode + unicycle roll-out" + ("; RCCL all-gather of trajectories" if distributed else ""),
                    "scenes_per_gpu": args.scenes, "agents_per_scene": args.agents, "agents_per_gpu": B,
                    "denoise_steps": n, "cfg_guidance_w": args.cfg_w, "unet_passes_per_step": 2 if args.cfg_w else 1,

@@ -4,8 +4,9 @@ The contract is upstream's `DiffuserTrafficModel.get_action` (`src/tbsim/algos/a
 returns `(Action(positions [B,T,2], yaws [B,T,1]), {"action_samples": {...}})`, sample 0 is the action,
 stationary agents are zeroed; `Action` is `src/tbsim/policies/common.py:10-66`.
 
-`ContextEncoder` (raster -> cond_feat) is not built: `obs_dict` must already carry `cond_feat`
-[B,256] and `curr_states` [B,4], or a `context_encoder` callable producing them is passed in.
+`obs_dict` is either the reference's observation batch (`image` [B,34,224,224], `history_positions`, `history_yaws`,
+`curr_speed`: the `ContextEncoder` of `context_utils.py` turns it into `cond_feat` / `curr_states` on the device), or
+already carries `cond_feat` [B,256] and `curr_states` [B,4]; a different `context_encoder` callable may be passed in.
 Parity: unpinned in the reference (no CLD implementation exists); tests check the composition against the
 oracle's sample/decode chain and the world update against a NumPy restatement of `env_trajdata.py:452-468`.
 """
@@ -57,12 +58,15 @@ class CldPolicy:
 
     @torch.no_grad()
     def get_action(self, obs_dict: Mapping, num_action_samples: int = 1, class_free_guide_w: float = 0.0,
-                   step_index: int = 0, noise: Optional[Mapping] = None, **kwargs):
-        aux = self.context_encoder(obs_dict) if self.context_encoder else obs_dict
+                   step_index: int = 0, noise: Optional[Mapping] = None, guidance: Optional[Mapping] = None, **kwargs):
+        if "cond_feat" in obs_dict:
+            aux = obs_dict
+        else:                                                       # obs -> aux_info (vae_model.py:84-88 pre_vae)
+            aux = (self.context_encoder or self.vae.context_encoder)(obs_dict)
         cond, cs = aux["cond_feat"], aux["curr_states"]
         B, N = cond.shape[0], int(num_action_samples)
         out = self.dm({"history_positions": cond}, {k: aux[k] for k in ("cond_feat", "curr_states", "non_cond_feat") if k in aux},
-                      {"num_samp": N}, noise=noise, class_free_guide_w=class_free_guide_w)
+                      {"num_samp": N}, noise=noise, class_free_guide_w=class_free_guide_w, guidance=guidance)
         a = out["aux_info"]
         traj = self.vae.engine.decode(out["pred_traj"], a["cond_feat"], a["curr_states"], descaled_output=True)
         traj = traj.reshape(B, N, 52, 6)

@@ -347,3 +347,27 @@ def test_reward_golden_and_oracle(golden, eng_jitter):
     # no other agents: collision term vanishes
     r2, _, c2 = eng_jitter.compute_reward(ri["traj"], ri["traj_scaled"], ri["raster_from_agent"], ri["drivable_map"])
     assert float(c2.abs().max()) == 0.0
+
+
+def test_get_action_from_raw_observation(eng_ctx):
+    """The policy surface on the reference's observation batch (image + history): get_action must equal
+    context_encode -> sample -> decode composed by hand (bit for bit: same kernels, same inputs)."""
+    from cld_amd.dm_model import DmModel
+    from cld_amd.policy import CldPolicy
+    from cld_amd.vae_model import VaeModel
+    eng = eng_ctx.__class__(n_timesteps=10, device="cuda:0")
+    for sd in (synth.make_unet_weights(0), synth.make_decoder_weights(0), synth.make_context_weights(0)):
+        eng.load_state_dict(sd)
+    eng.finalize()
+    dm, vae = DmModel(None, None, n_timesteps=10, engine=eng), VaeModel(engine=eng)
+    B = 3
+    obs = {"history_positions": torch.zeros(B, 31, 2), "history_yaws": torch.zeros(B, 31, 1),
+           "curr_speed": torch.from_numpy(synth.uniform(2, "curr_speed", (B,), 0.0, 15.0)),
+           "image": torch.from_numpy(synth.make_raster(B, 2)).cuda()}
+    nz = synth.make_noise(B, 10, 9)
+    noise = {"x_T": torch.from_numpy(nz["x_T"]), "noise": torch.from_numpy(nz["noise"])}
+    act, info = CldPolicy(dm, vae).get_action(obs, noise=noise)
+    aux = vae.context_encoder(obs)
+    x0, _, _ = eng.sample(noise["x_T"], aux["cond_feat"], noise=noise["noise"])
+    traj = eng.decode(x0, aux["cond_feat"], aux["curr_states"], descaled_output=True)
+    assert torch.equal(act.positions, traj[..., :2]) and torch.equal(act.yaws, traj[..., 3:4])
