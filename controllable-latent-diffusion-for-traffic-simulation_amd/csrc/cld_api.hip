@@ -40,6 +40,7 @@ struct ConvLayer {
 };
 
 struct ResBlock { ConvLayer c0, c1, res; bool has_res = false; };
+constexpr long kProfStride = 10;
 const char* const kResnet = "context_encoder.map_encoder.encoder_heads.map_model.";
 
 }  // namespace
@@ -76,6 +77,7 @@ struct cld_handle_s {
     // diagnostic (-DCLD_STAMPS builds): launch index within a U-Net evaluation that receives the stamp buffer
     unsigned long long* stamp_buf = nullptr;
     int stamp_layer = -1, launch_counter = 0;
+    long eval_counter = 0;               // U-Net evaluations since profile_enable: every kProfStride-th one is timed
 };
 
 namespace {
@@ -321,7 +323,9 @@ hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const flo
     h->launch_counter++;
     ConvGeom g;
     if (!pick_tiling(l, b_pad, &g)) return hipErrorInvalidValue;
-    const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && l.c_out == 256;   // the dominant layer shape
+    // the dominant layer shape, in every kProfStride-th U-Net evaluation: an event pair costs ~2 us of stream time, and
+    // bracketing all 700 launches of a 100-step sample call slowed the timed region itself by 5 %
+    const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && l.c_out == 256 && (h->eval_counter % kProfStride) == 0;
     if (!timed) return launch_conv(g, a, b_pad, s);
     if (h->prof_used + 2 > h->prof_ev.size()) {
         for (int i = 0; i < 2; ++i) {
@@ -347,6 +351,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     const float* tbr = h->tb + (size_t)t_idx * NCB;
     float* const* b = w.buf;
     h->launch_counter = 0;
+    h->eval_counter++;
     hipError_t e;
 #define RC(...) do { e = run_conv(h, __VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
     auto resblock = [&](const ResBlock& rb, const float* in1, const float* in2, float* out) -> hipError_t {
@@ -452,6 +457,7 @@ int cld_profile_enable(cld_handle h, int32_t on) {
     if (!h) return CLD_ERR_ARG;
     h->prof_on = on != 0;
     h->prof_used = 0;
+    h->eval_counter = -1;
     h->prof_flop = 0.0;
     return CLD_OK;
 }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     const size_t img_bytes = (size_t)CIN * HIN * HIN * 4;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(image) + (size_t)b * CIN * HIN * HIN, 0, (int)img_bytes, 0x00020000);
-    int voff[NPIECE], soff[NPIECE];
+    int voff[NPIECE], soff[NPIECE], pmask[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
         const int idx = tid + 256 * i;
@@ -70,6 +70,13 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         const bool in = ok && irow >= 0 && irow < HIN;
         voff[i] = in ? (irow * HIN + 4 * c4) * 4 : (int)img_bytes;      // out of range -> the buffer load returns 0
         soff[i] = ok ? row * RS + 3 + 4 * c4 : -1;
+        // output-column blocks (16 output columns = one M-tile per row) whose 7-wide windows can see this piece:
+        // block cb reads strip columns [32 cb, 32 cb + 36]
+        const int lo = 3 + 4 * c4, hi = lo + 3;
+        int mk = 0;
+#pragma unroll
+        for (int cb = 0; cb < 7; ++cb) mk |= (32 * cb <= hi && 32 * cb + 36 >= lo) ? (1 << cb) : 0;
+        pmask[i] = mk;
     }
     // zero the 3-column halos of both images once (never overwritten)
     for (int i = tid; i < 2 * PRW * 6; i += 256) {
@@ -82,19 +89,24 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         for (int i = 0; i < NPIECE; ++i) st[i] = cbuf_load16(rsx, voff[i], c * (HIN * HIN * 4));
     };
     // The history planes of the raster are almost empty (one +1 pixel for the agent and a -1 per neighbour,
-    // trajdata_utils.py:123-156): a strip that is all zeros adds exactly nothing, so its 182 MFMAs per wave are skipped.
-    // Exact for any input (a zero strip contributes +-0 to every sum); dense rasters simply never take the shortcut.
+    // trajdata_utils.py:123-156): a 16-column output block whose input window of this plane is all zeros receives exactly
+    // nothing from it, so its 26 MFMAs per wave are skipped; plane_nz[c] is the 7-bit mask of blocks that do see a
+    // non-zero value.  Exact for any input (a zero window contributes +-0 to every sum); dense rasters keep the full loop.
     auto store_plane = [&](int bufi, int c) {
-        bool nz = false;
+        int mk = 0;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
-            nz |= (st[i][0] != 0.f) | (st[i][1] != 0.f) | (st[i][2] != 0.f) | (st[i][3] != 0.f);
+            const bool nz = (st[i][0] != 0.f) | (st[i][1] != 0.f) | (st[i][2] != 0.f) | (st[i][3] != 0.f);
+            mk |= nz ? pmask[i] : 0;
             if (soff[i] >= 0) {
                 float* d = lds + bufi * BUF + soff[i];
                 d[0] = st[i][0]; d[1] = st[i][1]; d[2] = st[i][2]; d[3] = st[i][3];
             }
         }
-        if (__builtin_amdgcn_ballot_w64(nz) != 0 && lane == 0) plane_nz[c] = 1;
+        int wm = 0;
+#pragma unroll
+        for (int cb = 0; cb < 7; ++cb) wm |= (__builtin_amdgcn_ballot_w64((mk >> cb) & 1) != 0) ? (1 << cb) : 0;
+        if (wm && lane == 0) atomicOr(&plane_nz[c], wm);
     };
 
     // per-lane LDS byte offsets of the 13 k-steps: tap k = 4q + kk -> (kh, kw); pixel column 2 * i16
@@ -124,18 +136,48 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
             const int c = c0 + cu;
             const bool more = c + 1 < CIN;
             if (more) load_plane(c + 1);
-            if (__builtin_amdgcn_readfirstlane(plane_nz[c])) {
+            const int blocks = __builtin_amdgcn_readfirstlane(plane_nz[c]);
+            if (blocks) {
                 v4f bq[4];
 #pragma unroll
                 for (int qg = 0; qg < 4; ++qg) bq[qg] = wq4[(c * 4 + qg) * 256];
+                if (blocks == 0x7f) {
+                    // the 14 A values of k-step q+1 are read while k-step q's MFMAs issue (one ds_read_b32 behind each MFMA, pinned)
+                    float av[2][SMT];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const float bv = bq[q >> 2][q & 3];
+                    for (int m = 0; m < SMT; ++m)
+                        av[0][m] = *reinterpret_cast<const float*>(ldsb + qoff[0] + cu * BUF * 4 + (2 * (m / 7) * RS + 32 * (m % 7)) * 4);
 #pragma unroll
-                    for (int m = 0; m < SMT; ++m) {
-                        const int imm = cu * BUF * 4 + (2 * (m / 7) * RS + 32 * (m % 7)) * 4;
-                        const float av = *reinterpret_cast<const float*>(ldsb + qoff[q] + imm);
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m], 0, 0, 0);
+                    for (int q = 0; q < NQ; ++q) {
+                        const int cur = q & 1;
+                        const float bv = bq[q >> 2][q & 3];
+#pragma unroll
+                        for (int m = 0; m < SMT; ++m) {
+                            const int imm = cu * BUF * 4 + (2 * (m / 7) * RS + 32 * (m % 7)) * 4;
+                            if (q + 1 < NQ) av[cur ^ 1][m] = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm);
+                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][m], bv, acc[m], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+                    // sparse plane: only the column blocks that see a non-zero value (both rows of the block: M-tiles cb, cb + 7)
+#pragma unroll
+                    for (int cb = 0; cb < 7; ++cb) {
+                        if (!((blocks >> cb) & 1)) continue;
+                        const int imm0 = cu * BUF * 4 + (32 * cb) * 4, imm1 = imm0 + 2 * RS * 4;
+                        float a0 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm0);
+                        float a1 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm1);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const float bv = bq[q >> 2][q & 3];
+                            const float c0v = a0, c1v = a1;
+                            if (q + 1 < NQ) {
+                                a0 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm0);
+                                a1 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm1);
+                            }
+                            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0v, bv, acc[cb], 0, 0, 0);
+                            acc[cb + 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1v, bv, acc[cb + 7], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -304,16 +346,25 @@ __global__ __launch_bounds__(256) void conv2d_kernel(const Conv2dArgs p) {
         const bool more = c + 1 < nchunk;
         if (more) load_chunk(c + 1);
         const int boff = bufi * G::IMG * 4;
+        // fragments of tap t+1 are read while tap t's MFMAs issue: one ds_read_b128 behind every 4 MFMAs, pinned with
+        // sched_barrier (left alone the compiler bunches the reads in front of each tap and the MFMA pipe starts every
+        // tap behind an LDS bubble); weight fragments run one tap ahead
         v4f bcur = cbuf_load16(rsw, wlane, ((c * G::NTAPS + 0) * ntn + ntile_g) * 1024);
+        v4f af[2][G::NMT];
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + boff);
 #pragma unroll
         for (int t = 0; t < G::NTAPS; ++t) {
-            const v4f bnext = (t + 1 < G::NTAPS) ? cbuf_load16(rsw, wlane, ((c * G::NTAPS + t + 1) * ntn + ntile_g) * 1024) : bcur;
-            const int toff = ((t / KH) * G::PW + (t % KH)) * G::SROW * 4;
+            const int cur = t & 1;
+            const bool nxt = t + 1 < G::NTAPS;
+            const v4f bnext = nxt ? cbuf_load16(rsw, wlane, ((c * G::NTAPS + t + 1) * ntn + ntile_g) * 1024) : bcur;
+            const int toff = (((t + 1) / KH) * G::PW + ((t + 1) % KH)) * G::SROW * 4;
 #pragma unroll
             for (int m = 0; m < G::NMT; ++m) {
-                const v4f av = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + boff + toff);
+                if (nxt) af[cur ^ 1][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + boff + toff);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bcur[e], acc[m], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][m][e], bcur[e], acc[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             bcur = bnext;
         }
