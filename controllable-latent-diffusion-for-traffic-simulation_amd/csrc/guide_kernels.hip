@@ -323,10 +323,336 @@ static int guide_grid(int B) {
     const int groups = (B + GNA - 1) / GNA;
     return groups < 512 ? groups : 512;
 }
-size_t guide_scratch_floats(int B) { return (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS); }
+
+// =============================================================================================
+// MFMA formulation: 16 agents per workgroup, the recurrent products as v_mfma_f32_16x16x4_f32 tiles
+// =============================================================================================
+// Wave w owns hidden units 16w..16w+15 of BOTH layers.  For a layer step the gate pre-activations of 16 agents are the
+// GEMM [16 agents x K] x [K x 256]; wave w computes the four 16-column N-tiles {i, f, g, o} of ITS units, so the MFMA
+// result layout (lane = (unit n, agent block rb), 4 registers = agents 4rb..4rb+3) already holds all four gates of one
+// (agent, unit) cell in one lane: the cell update runs in registers and only h goes through LDS (the A operand of the next
+// product) -- two barriers per time step.  The backward products dG x W ([16 x 256] x [256 x 64]) come out in the same
+// layout, so the recurrent gradients stay in registers too; only the gate gradients pass through LDS.
+// A operands are read as float4 (4 consecutive k per lane, element e feeds MFMA e), B fragments use the same k permutation.
+namespace gm {
+constexpr int AG = 16;                  // agents per workgroup
+constexpr int HS = 68;                  // LDS row stride of the h tiles (68 / 4 odd: conflict-free b128 rows)
+constexpr int GS = 260;                 // LDS row stride of the gate-gradient tiles
+constexpr int ACTS = GT * 2 * 5 * 4 * 256;   // floats of kept activations per workgroup: [t][layer][i f g o c][r][thread]
+}  // namespace gm
+
+__device__ __forceinline__ float fsig(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+__global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
+    using namespace gm;
+    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
+    __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
+    __shared__ __attribute__((aligned(16))) float zin[AG][208];
+    __shared__ __attribute__((aligned(16))) float condm[AG][256];
+    __shared__ float actp[GT][4][AG];        // per-wave partials of the acceleration output
+    __shared__ float dact[AG][GT];
+    __shared__ float dzp[2][4][AG][4];       // per-wave partials of dL/dz_t, by step parity
+    __shared__ float dz[AG][208];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, rb = lane >> 4;        // MFMA layouts: A lane = (row n, k kk = rb); B lane = (col n, k rb); D lane = (col n, rows 4rb..4rb+3)
+    const int u = 16 * wv + n;                      // this lane's hidden unit
+    const float wa0 = w.w_h2a[u], bh2a = w.b_h2a[0];
+
+    const int ngroups = (a.B + AG - 1) / AG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * AG;
+        float* keep = a.scratch + (size_t)blockIdx.x * ACTS;
+        auto agent = [&](int ag) { return (b0 + ag < a.B) ? b0 + ag : a.B - 1; };      // tail slots replay the last agent; never stored
+        for (int i = tid; i < AG * 256; i += 256) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
+        for (int i = tid; i < AG * 208; i += 256) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
+        __syncthreads();
+        for (int i = tid; i < AG * 64; i += 256) {      // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49)
+            const int ag = i >> 6, uu = i & 63;
+            float s = w.b_c2h[uu];
+            const float* wr = w.w_c2h + uu * 256;
+            for (int k = 0; k < 256; ++k) s = fmaf(condm[ag][k], wr[k], s);
+            hs[0][0][ag][uu] = s;
+            hs[1][0][ag][uu] = s;
+        }
+        float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        // ---------------- forward ----------------
+        {
+            int nn = n;
+            asm volatile("" : "+v"(nn));       // keeps the weight loads of this phase inside the group loop (see guide_kernel)
+            // B fragments: gate g', k-step (j, e) -> W[col = 64 g' + 16 wv + n][k = 16 j + 4 rb + e]
+            float f_hh0[4][4][4], f_ih1[4][4][4], f_hh1[4][4][4], f_ih0[4], fb0[4], fb1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 64 * g + 16 * wv + nn;
+                f_ih0[g] = w.w_ih0[col * 4 + rb];
+                fb0[g] = w.b0[col];
+                fb1[g] = w.b1[col];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 64 * g + 16 * wv + nn;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const v4f x0 = *reinterpret_cast<const v4f*>(w.w_hh0 + col * 64 + 16 * jj + 4 * rb);
+                    const v4f x1 = *reinterpret_cast<const v4f*>(w.w_ih1 + col * 64 + 16 * jj + 4 * rb);
+                    const v4f x2 = *reinterpret_cast<const v4f*>(w.w_hh1 + col * 64 + 16 * jj + 4 * rb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { f_hh0[g][jj][e] = x0[e]; f_ih1[g][jj][e] = x1[e]; f_hh1[g][jj][e] = x2[e]; }
+                }
+            }
+            for (int t = 0; t < GT; ++t) {
+                const int pr = t & 1;
+                // ---- layer 0: pre = b + x_t W_ih0^T + h0_{t-1} W_hh0^T ----
+                v4f acc[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = v4f{fb0[g], fb0[g], fb0[g], fb0[g]};
+                {
+                    const float xa = zin[n][4 * t + rb];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f_ih0[g], acc[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_hh0[g][jj][e], acc[g], 0, 0, 0);
+                }
+                float* kp = keep + (size_t)(t * 2 + 0) * (5 * 4 * 256) + tid;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ig = fsig(acc[0][r]), fg = fsig(acc[1][r]), gg = ftanh(acc[2][r]), og = fsig(acc[3][r]);
+                    const float c = fg * c0[r] + ig * gg;
+                    c0[r] = c;
+                    hs[0][pr ^ 1][4 * rb + r][u] = og * ftanh(c);
+                    kp[(0 * 4 + r) * 256] = ig; kp[(1 * 4 + r) * 256] = fg; kp[(2 * 4 + r) * 256] = gg; kp[(3 * 4 + r) * 256] = og;
+                    kp[(4 * 4 + r) * 256] = c;
+                }
+                __syncthreads();
+                // ---- layer 1: pre = b + h0_t W_ih1^T + h1_{t-1} W_hh1^T ----
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = v4f{fb1[g], fb1[g], fb1[g], fb1[g]};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][n][16 * jj + 4 * rb]);
+                    const v4f hb = *reinterpret_cast<const v4f*>(&hs[1][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[g][jj][e], acc[g], 0, 0, 0);
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[g][jj][e], acc[g], 0, 0, 0);
+                        }
+                }
+                kp += 5 * 4 * 256;
+                float ap[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ig = fsig(acc[0][r]), fg = fsig(acc[1][r]), gg = ftanh(acc[2][r]), og = fsig(acc[3][r]);
+                    const float c = fg * c1[r] + ig * gg;
+                    c1[r] = c;
+                    const float hn = og * ftanh(c);
+                    hs[1][pr ^ 1][4 * rb + r][u] = hn;
+                    kp[(0 * 4 + r) * 256] = ig; kp[(1 * 4 + r) * 256] = fg; kp[(2 * 4 + r) * 256] = gg; kp[(3 * 4 + r) * 256] = og;
+                    kp[(4 * 4 + r) * 256] = c;
+                    ap[r] = hn * wa0;                       // hid2act, acceleration channel: partial over this wave's 16 units
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ap[r] += __shfl_xor(ap[r], o);
+                if (n == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) actp[t][wv][4 * rb + r] = ap[r];
+                }
+                __syncthreads();
+            }
+        }
+        // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
+        if (tid < AG) {
+            const int b = agent(tid);
+            const float* cs = a.curr_states + (size_t)b * 4;
+            const float* tgt = a.target_speed + (size_t)b * GT;
+            const float scale = a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT);
+            float v_raw = cs[2];
+            for (int t = 0; t < GT; ++t) {
+                const float as = actp[t][0][tid] + actp[t][1][tid] + actp[t][2][tid] + actp[t][3][tid] + bh2a;
+                actp[t][0][tid] = as;
+                const float acc = as * d.std[4] + d.mean[4];
+                v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
+                const bool vok = v_raw >= d.v_lo && v_raw <= d.v_hi;
+                const float v = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
+                const float df = v - tgt[t];
+                const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+                dact[tid][t] = vok ? scale * sgn : 0.f;
+            }
+            float run = 0.f;
+            for (int t = GT - 1; t >= 0; --t) {
+                run += dact[tid][t];
+                const float acc = actp[t][0][tid] * d.std[4] + d.mean[4];
+                dact[tid][t] = (acc >= d.acc_lo && acc <= d.acc_hi) ? run * d.dt * d.std[4] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---------------- backward through time ----------------
+        {
+            int nn = n;
+            asm volatile("" : "+v"(nn));
+            // B fragments of the transposed products: k-step (j, e) -> gate column col = 16 j + 4 rb + e, output unit 16 wv + n
+            float t_hh1[16][4], t_ih1[16][4], t_hh0[16][4], t_ih0[4][4];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int col = 16 * jj + 4 * rb + e;
+                    t_hh1[jj][e] = w.w_hh1[col * 64 + 16 * wv + nn];
+                    t_ih1[jj][e] = w.w_ih1[col * 64 + 16 * wv + nn];
+                    t_hh0[jj][e] = w.w_hh0[col * 64 + 16 * wv + nn];
+                }
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq)        // dL/dz: wave wv reduces gate columns 64 wv .. 64 wv + 63 (N = 4 latent channels, padded)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t_ih0[jq][e] = nn < 4 ? w.w_ih0[(64 * wv + 16 * jq + 4 * rb + e) * 4 + nn] : 0.f;
+            float rec1[4] = {0.f, 0.f, 0.f, 0.f}, rec0[4] = {0.f, 0.f, 0.f, 0.f};
+            float dc1n[4] = {0.f, 0.f, 0.f, 0.f}, dc0n[4] = {0.f, 0.f, 0.f, 0.f};
+            // kept activations of one (step, layer): i f g o c of 4 agents + the previous cell state; fetched from the
+            // L2-resident scratch one phase ahead, in flight under the MFMA block that precedes their use
+            float kv1[6][4], kv0[6][4];
+            auto fetch = [&](float (&kv)[6][4], int t, int layer) {
+                const float* kp = keep + (size_t)(t * 2 + layer) * (5 * 4 * 256) + tid;
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kv[q][r] = kp[(q * 4 + r) * 256];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kv[5][r] = t > 0 ? kp[(4 * 4 + r) * 256 - 2 * (5 * 4 * 256)] : 0.f;
+            };
+            fetch(kv1, GT - 1, 1);
+            for (int t = GT - 1; t >= 0; --t) {
+                // ---- layer 1 gate gradients -> LDS ----
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ig = kv1[0][r], fg = kv1[1][r], gg = kv1[2][r], og = kv1[3][r], c = kv1[4][r], cp = kv1[5][r];
+                    const float tc = ftanh(c);
+                    const float dh = wa0 * dact[4 * rb + r][t] + rec1[r];
+                    const float dc = dh * og * (1.f - tc * tc) + dc1n[r];
+                    float* row = &dG[0][4 * rb + r][u];
+                    row[0] = dc * gg * ig * (1.f - ig);
+                    row[64] = dc * cp * fg * (1.f - fg);
+                    row[128] = dc * ig * (1.f - gg * gg);
+                    row[192] = dh * tc * og * (1.f - og);
+                    dc1n[r] = dc * fg;
+                }
+                __syncthreads();
+                fetch(kv0, t, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                v4f pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const v4f ga = *reinterpret_cast<const v4f*>(&dG[0][n][16 * jj + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pa = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_hh1[jj][e], pa, 0, 0, 0);     // -> rec1 of step t-1
+                        pb = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_ih1[jj][e], pb, 0, 0, 0);     // -> dL/dh0_t from layer 1
+                    }
+                }
+                // ---- layer 0 gate gradients -> LDS ----
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    rec1[r] = pa[r];
+                    const float ig = kv0[0][r], fg = kv0[1][r], gg = kv0[2][r], og = kv0[3][r], c = kv0[4][r], cp = kv0[5][r];
+                    const float tc = ftanh(c);
+                    const float dh = pb[r] + rec0[r];
+                    const float dc = dh * og * (1.f - tc * tc) + dc0n[r];
+                    float* row = &dG[1][4 * rb + r][u];
+                    row[0] = dc * gg * ig * (1.f - ig);
+                    row[64] = dc * cp * fg * (1.f - fg);
+                    row[128] = dc * ig * (1.f - gg * gg);
+                    row[192] = dh * tc * og * (1.f - og);
+                    dc0n[r] = dc * fg;
+                }
+                __syncthreads();
+                if (t > 0) fetch(kv1, t - 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                v4f pc = {0.f, 0.f, 0.f, 0.f}, pz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const v4f ga = *reinterpret_cast<const v4f*>(&dG[1][n][16 * jj + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_hh0[jj][e], pc, 0, 0, 0);   // -> rec0 of step t-1
+                }
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    const v4f ga = *reinterpret_cast<const v4f*>(&dG[1][n][64 * wv + 16 * jq + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_ih0[jq][e], pz, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec0[r] = pc[r];
+                if (n < 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dzp[t & 1][wv][4 * rb + r][n] = pz[r];
+                }
+                // the partials of step t+1 (other parity) are complete: both barriers of this step lie behind their writes
+                if (t + 1 < GT && tid < AG * 4) {
+                    const int ag = tid >> 2, k = tid & 3, q = (t + 1) & 1;
+                    dz[ag][4 * (t + 1) + k] = dzp[q][0][ag][k] + dzp[q][1][ag][k] + dzp[q][2][ag][k] + dzp[q][3][ag][k];
+                }
+            }
+            __syncthreads();
+            if (tid < AG * 4) {
+                const int ag = tid >> 2, k = tid & 3;
+                dz[ag][k] = dzp[0][0][ag][k] + dzp[0][1][ag][k] + dzp[0][2][ag][k] + dzp[0][3][ag][k];
+            }
+        }
+        __syncthreads();
+        // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
+        for (int i = tid; i < AG * 208; i += 256) {
+            const int ag = i / 208, r = i % 208, b = b0 + ag;
+            if (b >= a.B) continue;
+            const float g = dz[ag][r];
+            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
+            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
+            const float mu = zin[ag][r] + delta;
+            if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
+            if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
+            if (a.x_out) {
+                float zz = 0.f;
+                if (a.sigma != 0.f) zz = a.z ? a.z[(size_t)b * 208 + r] : normal4(a.seed, a.step_salt, (unsigned)(b * 52 + (r >> 2)))[r & 3];
+                const float xn = mu + a.sigma * zz;
+                a.x_out[(size_t)b * 208 + r] = xn;
+                if (a.x_out2) a.x_out2[(size_t)b * 208 + r] = xn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int guide_mfma_grid(int B) {
+    const int groups = (B + gm::AG - 1) / gm::AG;
+    return groups < 256 ? groups : 256;
+}
+// The MFMA kernel needs >= 16 agents per workgroup to pay off and one workgroup per CU to fill the chip: from 512 agents
+// (32 workgroups) up it is faster than the 2-agent VALU kernel (CLD_GUIDE_KERNEL=valu|mfma overrides, experiments only).
+static bool use_mfma_guide(int B) {
+    const char* force = getenv("CLD_GUIDE_KERNEL");
+    if (force && force[0] == 'v') return false;
+    if (force && force[0] == 'm') return true;
+    return B >= 512;
+}
+size_t guide_scratch_floats(int B) {
+    const size_t valu = (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS);
+    const size_t mfma = (size_t)guide_mfma_grid(B) * gm::ACTS;
+    return valu > mfma ? valu : mfma;
+}
 
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
+    if (use_mfma_guide(a.B)) hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a);
+    else hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
     return hipGetLastError();
 }
 

@@ -371,3 +371,30 @@ def test_get_action_from_raw_observation(eng_ctx):
     x0, _, _ = eng.sample(noise["x_T"], aux["cond_feat"], noise=noise["noise"])
     traj = eng.decode(x0, aux["cond_feat"], aux["curr_states"], descaled_output=True)
     assert torch.equal(act.positions, traj[..., :2]) and torch.equal(act.yaws, traj[..., 3:4])
+
+
+def test_guidance_mfma_kernel_vs_oracle_and_valu(eng_jitter):
+    """The 16-agents-per-workgroup MFMA formulation of the guidance kernel (taken from 512 agents up): gradient against the
+    oracle's autograd at B = 520 (ragged last tile), and against the 2-agent VALU kernel on the same inputs."""
+    import os
+    from oracle import cld_oracle as O
+    B = 520
+    inp = synth.make_inputs(B, 21)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    mean = torch.from_numpy(synth.normal(21, "guide_mean", (B, 52, 4)))
+    tgt = torch.from_numpy(synth.uniform(21, "guide_target_speed", (B, 52), 0.0, 12.0))
+    gd = {"curr_states": cs, "target_speed": tgt, "lr": 2.0, "perturb_th": None, "optimizer": "sgd"}
+    outs = {}
+    for k in ("mfma", "valu"):
+        os.environ["CLD_GUIDE_KERNEL"] = k
+        try:
+            outs[k] = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["CLD_GUIDE_KERNEL"]
+    torch.set_num_threads(8)
+    _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, tgt, None, 2.0, None, "sgd")
+    gmax = gref.abs().max().item()
+    assert (outs["mfma"][1].cpu() - gref).abs().max().item() <= 2e-5 * gmax
+    assert (outs["valu"][1].cpu() - gref).abs().max().item() <= 2e-5 * gmax
+    assert (outs["mfma"][0] - outs["valu"][0]).abs().max().item() <= 2.0 * 4e-5 * gmax + 2.5e-7

@@ -196,3 +196,33 @@ def test_get_action_and_closed_loop(eng, oracle_w):
     # 3 closed-loop sim steps stay finite and move the non-stationary agents
     poses = closed_loop_rollout(CldPolicy(dm, vae), lambda s, wld, c: cond, centroid, yaw, cs, n_sim_steps=3)
     assert poses.shape == (3, B, 3) and bool(torch.isfinite(poses).all())
+
+
+def test_sampling_call_is_graph_capturable(eng):
+    """include/cld.h promises that the compute calls neither allocate nor synchronise, so a whole 100-step sampling call
+    (~3,000 launches) can be captured into a HIP graph and replayed: the replay must reproduce the eager result bit for bit,
+    also after the inputs are overwritten in place."""
+    B = 48
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, 52, 4, device="cuda", generator=g)
+    c = torch.randn(B, 256, device="cuda", generator=g)
+    z = torch.randn(100, B, 52, 4, device="cuda", generator=g)
+    eager = eng.sample(x, c, noise=z)[0].clone()
+    torch.cuda.synchronize()                           # the engine's workspace is shared: no overlap with the capture stream
+    s = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        eng.sample(x, c, noise=z)                      # warm-up on the capture stream (workspace, kernel attributes)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gr, stream=s):
+            out = eng.sample(x, c, noise=z)
+    torch.cuda.synchronize()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], eager)
+    x2 = torch.randn(B, 52, 4, device="cuda", generator=g)
+    eager2 = eng.sample(x2, c, noise=z)[0].clone()
+    x.copy_(x2)                                        # same buffers, new contents
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], eager2)
