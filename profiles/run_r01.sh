@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-1 profile set (run on the GPU box from the repo root):  bash profiles/run_r01.sh
-# Kernel-trace stats of the default bench command, the bench lines themselves, the ContextEncoder pass, and the PMC passes
-# (separate runs, --kernel-trace only) for the dominant kernel.  Everything lands under gpurun_out/r01/; the summaries
-# are copied into profiles/r01/ by hand afterwards.
+# Bench lines, kernel-trace stats of the default bench command and of a ContextEncoder pass, batch sweep, and the PMC
+# passes (separate runs, --kernel-trace + --pmc only) for the conv kernels and the stem.  Everything lands under
+# gpurun_out/r01/; profiles/summarize_r01.py condenses it into profiles/r01/.
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r01
 mkdir -p $OUT
@@ -16,4 +16,10 @@ python3 $R/bench.py --closed-loop 20 --denoise-steps 50 --scenes 64 --agents 64 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats -o bench -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/kstats.log 2>&1 && \
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kstats_ctx -o ctx -- python3 $R/scripts/ctx_time.py 256 > $OUT/kstats_ctx.log 2>&1 && \
 python3 $R/scripts/sweep_batch.py > $OUT/batch_sweep.txt 2>&1
-ls -R $OUT | head -40
+ARGS="$R/bench.py --steps 1 --warmup 0 --denoise-steps 10 --no-cpu-baseline --no-profile --no-context"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o p -- python3 $ARGS > $OUT/pmc_sq.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_write -o p -- python3 $ARGS > $OUT/pmc_write.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_ctx_fetch -o p -- python3 $R/scripts/ctx_time.py 256 > $OUT/pmc_ctx_fetch.log 2>&1 && \
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_ctx_write -o p -- python3 $R/scripts/ctx_time.py 256 > $OUT/pmc_ctx_write.log 2>&1
+ls -R $OUT | head -60
