@@ -23,6 +23,13 @@ class LSTMVAE:
     def lstm_dec(self, z, context):
         return self.engine.lstm_decode(z, context)
 
+    def forward(self, x, context, noise=None):
+        """lstm_vae.py:82-85 -> (act_output [B,52,2], mean, logvar): encode, reparametrise, decode."""
+        z, mean, logvar = self.traj2z(x, context, noise)
+        return self.lstm_dec(z, context), mean, logvar
+
+    __call__ = forward
+
     def traj2z(self, x, context, noise=None):
         """lstm_vae.py:87-99 -> (z, mean, logvar).  `noise` replaces the reference's randn_like draw (:97);
         drawn from torch's device generator when omitted."""
@@ -53,6 +60,16 @@ class VaeModel:
         aux_info = self.context_encoder(batch)
         sa = self.get_state_and_action_from_data_batch(batch, scaled=False)
         return aux_info, self.get_state_and_action_from_data_batch(batch, scaled=True), sa
+
+    def forward(self, batch, beta=None, noise=None):
+        """VaeModel.forward (vae_model.py:64-82) without the loss terms (training is out of scope): the reconstruction
+        path pre_vae -> lstmvae -> convert_action_to_state_and_action -> descale, same dict keys for what is returned."""
+        aux_info, sa_scaled, _ = self.pre_vae(batch)
+        recon_act, mu, logvar = self.lstmvae(sa_scaled, aux_info["cond_feat"], noise)
+        recon = self.convert_action_to_state_and_action(recon_act, aux_info["curr_states"], descaled_output=True)
+        return {"hist": batch["history_positions"], "input": batch.get("target_positions"), "output": recon[..., :2],
+                "raster_from_agent": batch.get("raster_from_agent"), "image": batch["image"], "mu": mu, "logvar": logvar,
+                "recon_act": recon_act}
 
     def convert_action_to_state_and_action(self, x_out, curr_states, scaled_input=True, descaled_output=False):
         four_d = x_out.dim() == 4          # vae_model.py:108-111

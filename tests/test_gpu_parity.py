@@ -398,3 +398,35 @@ def test_guidance_mfma_kernel_vs_oracle_and_valu(eng_jitter):
     assert (outs["mfma"][1].cpu() - gref).abs().max().item() <= 2e-5 * gmax
     assert (outs["valu"][1].cpu() - gref).abs().max().item() <= 2e-5 * gmax
     assert (outs["mfma"][0] - outs["valu"][0]).abs().max().item() <= 2.0 * 4e-5 * gmax + 2.5e-7
+
+
+def test_vae_forward_reconstruction_path():
+    """VaeModel.forward (vae_model.py:64-82) minus the loss: pre_vae -> lstmvae (encode, reparametrise, decode) ->
+    convert_action_to_state_and_action, against the oracle's composition of the same pinned pieces."""
+    from cld_amd.engine import Engine
+    from cld_amd.vae_model import VaeModel
+    from oracle import cld_oracle as O
+    e = Engine(n_timesteps=10, device="cuda:0")
+    sds = [synth.make_unet_weights(0), synth.make_decoder_weights(0), synth.make_encoder_weights(0), synth.make_context_weights(0)]
+    for sd in sds:
+        e.load_state_dict(sd)
+    e.finalize()
+    vae = VaeModel(engine=e)
+    B = 3
+    fut = synth.make_future(B, 4)
+    img = torch.from_numpy(synth.make_raster(B, 4))
+    batch = {"history_positions": torch.zeros(B, 31, 2), "history_yaws": torch.zeros(B, 31, 1),
+             "curr_speed": torch.from_numpy(fut["curr_speed"]), "image": img.cuda(),
+             "target_positions": torch.from_numpy(fut["target_positions"]), "target_yaws": torch.from_numpy(fut["target_yaws"])}
+    nz = torch.from_numpy(synth.normal(4, "enc_noise", (B, 52, 4)))
+    out = vae.forward(batch, noise=nz)
+    w = {}
+    for sd in sds[1:]:
+        w.update(O.to_torch(sd))
+    cs = torch.zeros(B, 4); cs[:, 2] = batch["curr_speed"]
+    cond = O.context_encode(w, img, cs)
+    x6 = O.state_to_state_and_action(batch["target_positions"], batch["target_yaws"], batch["curr_speed"], scaled=True)
+    z, mu, lv = O.traj2z(w, x6, cond, nz)
+    ref = O.decode(w, z, cond, cs, descaled_output=True)
+    assert (out["mu"].cpu() - mu).abs().max().item() <= 5e-5 and (out["logvar"].cpu() - lv).abs().max().item() <= 5e-5
+    assert (out["output"].cpu() - ref[..., :2]).abs().max().item() <= 2e-4 * max(1.0, ref[..., :2].abs().max().item())

@@ -226,3 +226,31 @@ def test_sampling_call_is_graph_capturable(eng):
     gr.replay()
     torch.cuda.synchronize()
     assert torch.equal(out[0], eager2)
+
+
+def test_abi_error_paths_next_rows(eng):
+    """Error reporting of the context / guidance / reward entry points: status codes, never a crash."""
+    from cld_amd import _lib
+    lib = eng.lib
+    p = lambda t: C.c_void_p(t.data_ptr())
+    B = 2
+    img = torch.zeros(B, 34, 224, 224, device="cuda"); cs = torch.zeros(B, 4, device="cuda"); out = torch.empty(B, 256, device="cuda")
+    ws = torch.empty(int(lib.cld_context_workspace_bytes(eng._h, B)), dtype=torch.uint8, device="cuda")
+    # this engine has no context_encoder weights
+    assert lib.cld_context_encode(eng._h, p(img), p(cs), p(out), None, B, p(ws), ws.numel(), None) == -2
+    assert b"context_encoder" in lib.cld_last_error(eng._h)
+    mean = torch.zeros(B, 52, 4, device="cuda"); cond = torch.zeros(B, 256, device="cuda"); tgt = torch.zeros(B, 52, device="cuda")
+    big = torch.empty(int(lib.cld_workspace_bytes(eng._h, B)), dtype=torch.uint8, device="cuda")
+    g = _lib.CldGuidance(cs.data_ptr(), tgt.data_ptr(), None, 0.3, -1.0, 7)                    # unknown optimizer
+    assert lib.cld_guidance_step(eng._h, p(mean), p(cond), C.byref(g), 0.5, None, p(mean), None, None, B, p(big), big.numel(), None) == -1
+    g = _lib.CldGuidance(None, tgt.data_ptr(), None, 0.3, -1.0, 0)                             # missing curr_states
+    assert lib.cld_guidance_step(eng._h, p(mean), p(cond), C.byref(g), 0.5, None, p(mean), None, None, B, p(big), big.numel(), None) == -1
+    assert lib.cld_sample_guided(eng._h, p(mean), None, p(cond), None, 0.0, None, 100, p(mean), None, None, B, 0, p(big), big.numel(), None) == -1
+    R = torch.eye(3, device="cuda").repeat(B, 1, 1); dm = torch.ones(B, 8, 8, dtype=torch.uint8, device="cuda")
+    traj = torch.zeros(B, 52, 6, device="cuda")
+    assert lib.cld_compute_reward(eng._h, p(traj), None, p(R), p(dm), 8, 8, None, None, 3, 52, 0.8, p(out), None, None, B, None) == -1   # S > 0 without arrays
+    assert lib.cld_compute_reward(eng._h, p(traj), None, p(R), p(dm), 8, 8, None, None, 0, 0, 0.8, None, None, None, B, None) == -1        # no output
+    r = torch.empty(B, device="cuda")
+    assert lib.cld_compute_reward(eng._h, p(traj), None, p(R), p(dm), 8, 8, None, None, 0, 0, 0.8, p(r), None, None, B, None) == 0
+    torch.cuda.synchronize()
+    assert float(r.abs().max()) == 0.0                       # on the map, drivable everywhere, no neighbours, no jerk term

@@ -126,3 +126,34 @@ def test_gloo_world2_gather(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_context_host_mirror_and_synthetic_inputs():
+    """Host logic of the ContextEncoder row: curr_states assembly (batch_utils.py:46-65), state_dict key set, raster shape."""
+    from cld_amd import synth
+    from cld_amd.context_utils import get_current_states
+    B = 5
+    batch = {"history_positions": torch.randn(B, 31, 2), "history_yaws": torch.randn(B, 31, 1), "curr_speed": torch.rand(B)}
+    cs = get_current_states(batch)
+    assert cs.shape == (B, 4)
+    assert torch.equal(cs[:, :2], batch["history_positions"][:, -1]) and torch.equal(cs[:, 2], batch["curr_speed"])
+    assert torch.equal(cs[:, 3], batch["history_yaws"][:, -1, 0])
+    w = synth.make_context_weights(0)
+    assert len(w) == 130 and "context_encoder.map_encoder.encoder_heads.map_model.conv1.weight" in w
+    assert w["context_encoder.map_encoder.encoder_heads.map_model.conv1.weight"].shape == (64, 34, 7, 7)
+    assert w["context_encoder.process_cond_mlp._model.12.weight"].shape == (256, 256)
+    assert w["context_encoder.agent_state_encoder._model.1.weight"].shape == (64,)         # LayerNorm
+    r = synth.make_raster(2, 3)
+    assert r.shape == (2, 34, 224, 224) and float((r[:, :31] != 0).mean()) < 1e-3          # near-empty history planes
+    assert set(np.unique(r[:, 31:])) <= {0.0, 1.0}
+
+
+def test_guidance_struct_matches_header():
+    """ctypes mirror of `cld_guidance` (include/cld.h): three device pointers, two floats, one int32."""
+    from cld_amd import _lib
+    g = _lib.CldGuidance
+    assert [n for n, _ in g._fields_] == ["curr_states", "target_speed", "loss_scale", "lr", "perturb_th", "optimizer"]
+    assert ctypes.sizeof(g) == 40 and g.lr.offset == 24 and g.optimizer.offset == 32
+    hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
+    body = hdr[hdr.index("typedef struct cld_guidance {"):hdr.index("} cld_guidance;")]
+    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer);", body)] == [n for n, _ in g._fields_]
