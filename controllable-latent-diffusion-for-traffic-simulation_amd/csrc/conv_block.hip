@@ -108,7 +108,7 @@ __device__ __forceinline__ void s22_encode(const float (&v)[4], h4& hi, h4& lo) 
 // AIN / AOUT: activation format of the input / of the output and residual (0 = fp32, 1 = S22).  AIN = 1 selects the
 // split-precision loop: products hi*hi + hi*lo + lo*hi on the fp16 MFMA (weights pre-split and pre-scaled on the
 // host), fp32 accumulation -- measured indistinguishable from the exact-fp32 loop on this network
-// (scripts/emulate_split.py) at ~3.9x its in-loop rate (scripts/ubench/mfma_issue.hip, V5).
+// (tests/tools/emulate_split.py) at ~3.9x its in-loop rate (scripts/ubench/mfma_issue.hip, V5).
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const int bx, const int by) {
     constexpr bool SPLIT = AIN == 1;

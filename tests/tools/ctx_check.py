@@ -1,6 +1,6 @@
 """GPU check of cld_context_encode against the oracle (debug aid; the real tests live in tests/)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cld_amd import synth
 from cld_amd.engine import Engine

@@ -3,7 +3,7 @@ Every conv input activation and weight is replaced by hi + lo fp16 planes (22-bi
 hi*hi + hi*lo + lo*hi (lo*lo dropped), fp32 accumulation; activations are ALSO stored at 22 bits between
 layers (as the HIP path would).  Compares against the golden vectors recorded from the reference."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 from cld_amd import synth
 from oracle import cld_oracle as O
