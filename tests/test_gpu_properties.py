@@ -254,3 +254,30 @@ def test_abi_error_paths_next_rows(eng):
     assert lib.cld_compute_reward(eng._h, p(traj), None, p(R), p(dm), 8, 8, None, None, 0, 0, 0.8, p(r), None, None, B, None) == 0
     torch.cuda.synchronize()
     assert float(r.abs().max()) == 0.0                       # on the map, drivable everywhere, no neighbours, no jerk term
+
+
+def test_full_size_chain_vs_oracle(eng, oracle_w):
+    """BASELINE configs[1] at full size -- 32 x 32 = 1,024 agents, 100 steps, same noise -- directly against the oracle
+    (the GPU box's host cores finish it in ~10-20 s).  Bar: 1e-3 relative to max|x0| (the random-init chain
+    amplifies to |x0| ~ 1e4, where the reference disagrees with itself by 5e-7 relative across thread counts);
+    measured 1.8e-6.  Decoded trajectories: 1e-3 abs on O(100 m) positions; log_prob_final exact to 1e-4."""
+    O, w, wd = oracle_w
+    B, n = 1024, 100
+    inp, nz = synth.make_inputs(B, 1), synth.make_noise(B, n, 123)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    xT, z = torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"])
+    x0, x1, lp = eng.sample(xT, cond, noise=z)
+    traj = eng.decode(x0, cond, cs, descaled_output=True)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(16, __import__("os").cpu_count() or 1))
+    try:
+        with torch.no_grad():
+            ref = O.sample(w, O.schedule(n), xT, z, cond)
+            reft = O.decode(wd, ref["pred_traj"], cond, cs)
+    finally:
+        torch.set_num_threads(nthr)
+    scale = float(ref["pred_traj"].abs().max())
+    assert float((x0.cpu() - ref["pred_traj"]).abs().max()) <= 1e-3 * scale
+    assert float((x1.cpu() - ref["x1"]).abs().max()) <= 1e-3 * scale
+    assert float((traj.cpu() - reft).abs().max()) <= 1e-3
+    assert float((lp.cpu() - ref["log_prob_final"]).abs().max()) <= 1e-4
