@@ -81,22 +81,32 @@ class CldPolicy:
 
 
 def closed_loop_rollout(policy: CldPolicy, cond_fn: Callable, centroid, yaw, curr_states, n_sim_steps: int,
-                        n_step_action: int = 5, gather: Optional[Callable] = None, **get_action_kwargs):
+                        n_step_action: int = 5, gather: Optional[Callable] = None, timers=None, **get_action_kwargs):
     """The loop of `rollout_episodes` (`src/tbsim/utils/env_utils.py:255-304`) kept on the device:
     obs -> get_action -> take `n_step_action` steps of the plan -> new world pose -> re-plan.
     `cond_fn(step, world [B,3], curr_states [B,4]) -> cond_feat [B,256]` stands in for the observation +
-    ContextEncoder stage; `gather(traj)` (e.g. `parallel.gather_trajectories`) runs once per sim step so every
-    rank sees all agents' plans.  Returns the world poses after each sim step [n_sim_steps, B, 3]."""
+    ContextEncoder stage (it may return the raw observation batch instead: a dict with `image`, `history_*`,
+    `curr_speed`, which get_action runs through the ContextEncoder); `gather(traj)` (e.g. `parallel.gather_trajectories`)
+    runs once per sim step so every rank sees all agents' plans; `timers` (`cld_amd.timer.Timers`) collects the per-phase
+    times under the reference's keys "obs" / "network" / "env_step" / "step" (env_utils.py:268-298).
+    Returns the world poses after each sim step [n_sim_steps, B, 3]."""
+    from contextlib import nullcontext
+    tm = (lambda k: timers.timed(k)) if timers is not None else (lambda k: nullcontext())
     eng = policy.vae.engine
     world = torch.cat([torch.as_tensor(centroid), torch.as_tensor(yaw)[:, None]], dim=1).to(eng.device, torch.float32)
     cs = torch.as_tensor(curr_states).to(eng.device, torch.float32)
     poses = []
     for step in range(n_sim_steps):
-        obs = {"cond_feat": cond_fn(step, world, cs), "curr_states": cs}
-        _, info = policy.get_action(obs, step_index=step, **get_action_kwargs)
-        traj = info["trajectories"][:, 0].contiguous()
-        if gather is not None:
-            gather(traj)
-        world, cs = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), n_step_action - 1)
+        with tm("step"):
+            with tm("obs"):
+                o = cond_fn(step, world, cs)
+                obs = o if isinstance(o, Mapping) else {"cond_feat": o, "curr_states": cs}
+            with tm("network"):
+                _, info = policy.get_action(obs, step_index=step, **get_action_kwargs)
+                traj = info["trajectories"][:, 0].contiguous()
+            with tm("env_step"):
+                if gather is not None:
+                    gather(traj)
+                world, cs = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), n_step_action - 1)
         poses.append(world)
     return torch.stack(poses)

@@ -194,8 +194,13 @@ def test_get_action_and_closed_loop(eng, oracle_w):
         assert abs(float(world[b, 2]) - (yn[b] + trn[b, k, 3])) <= 1e-5
     assert torch.equal(ncs[:, 2], tr[:, k, 2]) and float(ncs[:, [0, 1, 3]].abs().max()) == 0.0
     # 3 closed-loop sim steps stay finite and move the non-stationary agents
-    poses = closed_loop_rollout(CldPolicy(dm, vae), lambda s, wld, c: cond, centroid, yaw, cs, n_sim_steps=3)
+    from cld_amd.timer import Timers
+    timers = Timers(device="cuda:0")
+    poses = closed_loop_rollout(CldPolicy(dm, vae), lambda s, wld, c: cond, centroid, yaw, cs, n_sim_steps=3, timers=timers)
     assert poses.shape == (3, B, 3) and bool(torch.isfinite(poses).all())
+    # per-phase timers under the reference's keys (env_utils.py:268-298); the network phase dominates on the device
+    assert all(k in timers._timers for k in ("obs", "network", "env_step", "step"))
+    assert timers.gpu_ms("network") > 10 * timers.gpu_ms("env_step") > 0.0 and timers.gpu_ms("step") >= timers.gpu_ms("network")
 
 
 def test_sampling_call_is_graph_capturable(eng):

@@ -157,3 +157,18 @@ def test_guidance_struct_matches_header():
     hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
     body = hdr[hdr.index("typedef struct cld_guidance {"):hdr.index("} cld_guidance;")]
     assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer);", body)] == [n for n, _ in g._fields_]
+
+
+def test_timers_keep_the_reference_surface():
+    """cld_amd.timer.Timers: tic / toc / timed / __str__ as src/tbsim/utils/timer.py:41-64 (host clock path, no GPU)."""
+    import time as _t
+    from cld_amd.timer import Timers
+    t = Timers()
+    for _ in range(3):
+        with t.timed("network"):
+            _t.sleep(0.002)
+    t.tic("obs"); t.toc("obs")
+    s = str(t)
+    assert s.startswith("network: ") and ", obs: " in s
+    assert t._timers["network"].calls == 3 and t._timers["network"].average_time >= 0.002
+    assert t.gpu_ms("network") == 0.0 and t.gpu_ms("missing") == 0.0
