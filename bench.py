@@ -53,6 +53,8 @@ def main():
                          "BASELINE configs[2]: --agents 64 --cfg-w 2.0 --guide)")
     ap.add_argument("--no-context", action="store_true",
                     help="skip the ContextEncoder (producer of cond_feat, SURVEY 8(f-1)) measurement / closed-loop stage")
+    ap.add_argument("--no-alt-precision", action="store_true",
+                    help="skip the secondary measurement of the same workload in the optional f16x2 split-precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     args = ap.parse_args()
@@ -235,6 +237,25 @@ def main():
             "note": "resnet18 [34,224,224] -> 256 + state / combine MLPs (models/context_utils.py:8-61), exact fp32 MFMA; "
                     "headline = structured synthetic raster (31 near-empty history planes + 3 semantic planes, "
                     "trajdata_utils.py:409-420); bound: MFMA (the 6.8 MB raster per agent is read once, in place)"}
+    if world == 1 and args.precision == "f32" and not args.no_alt_precision and not args.closed_loop:
+        # secondary, clearly labelled: the SAME workload in the optional split-precision mode (include/cld.h CLD_PRECISION_F16X2:
+        # fp16 hi+lo operand planes, 3 fp16 MFMAs per product, fp32 accumulate; same parity bars).  Never the headline value.
+        eng2 = Engine(n_timesteps=n, device=dev, precision="f16x2")
+        eng2.load_state_dict(synth.make_unet_weights(0)); eng2.load_state_dict(synth.make_decoder_weights(0)); eng2.finalize()
+
+        def alt_step():
+            x0, _, _ = eng2.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w, guidance=guidance)
+            return eng2.decode(x0, cond, cs, descaled_output=True)
+        alt_step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            alt_step()
+        torch.cuda.synchronize(dev)
+        adt = time.perf_counter() - t0
+        out["f16x2_mode"] = {"value": round(B * n * args.steps / adt, 1), "unit": "step·agent/s", "ms_per_step": round(adt / args.steps * 1e3, 3),
+                             "note": "optional split-precision mode (--precision f16x2), same workload and parity bars; not the headline"}
+        del eng2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(B)
     if rank == 0:
