@@ -77,6 +77,7 @@ struct cld_handle_s {
     // diagnostic (-DCLD_STAMPS builds): launch index within a U-Net evaluation that receives the stamp buffer
     unsigned long long* stamp_buf = nullptr;
     int stamp_layer = -1, launch_counter = 0;
+    size_t lds_floor = 0;                // experiments (cld_debug_lds_floor)
     long eval_counter = 0;               // U-Net evaluations since profile_enable: every kProfStride-th one is timed
 };
 
@@ -352,6 +353,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     float* const* b = w.buf;
     h->launch_counter = 0;
     h->eval_counter++;
+    set_lds_floor(h->lds_floor);
     hipError_t e;
 #define RC(...) do { e = run_conv(h, __VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
     auto resblock = [&](const ResBlock& rb, const float* in1, const float* in2, float* out) -> hipError_t {
@@ -450,6 +452,12 @@ int cld_debug_stamps(cld_handle h, void* buf, int32_t layer) {
     if (!h) return CLD_ERR_ARG;
     h->stamp_buf = static_cast<unsigned long long*>(buf);
     h->stamp_layer = layer;
+    return CLD_OK;
+}
+
+int cld_debug_lds_floor(cld_handle h, size_t bytes) {
+    if (!h) return CLD_ERR_ARG;
+    h->lds_floor = bytes;
     return CLD_OK;
 }
 

@@ -67,6 +67,7 @@ bool conv_geom_supported(const ConvGeom& g);
 // two independent convolutions with the same grid shape in ONE launch (blockIdx.z picks the role)
 hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s);
 bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
+void set_lds_floor(size_t bytes);      // experiments only: minimum dynamic LDS per conv launch (0 = off)
 
 // ---------------------------------------------------------------------------
 // small kernels (misc_kernels.hip)

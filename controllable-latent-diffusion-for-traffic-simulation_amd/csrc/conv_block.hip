@@ -574,6 +574,12 @@ __global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_pair_ker
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
+// Experiments only (cld_debug_lds_floor): a lower bound on the dynamic LDS a launch asks for, to steer how many
+// workgroups of which stream can share a CU.  0 = off.
+static size_t g_lds_floor = 0;
+void set_lds_floor(size_t bytes) { g_lds_floor = bytes; }
+static inline size_t lds_request(size_t need) { return g_lds_floor > need ? (g_lds_floor < 160 * 1024 ? g_lds_floor : 160 * 1024) : need; }
+
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = MT / LM;
@@ -585,12 +591,12 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 1);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_request(lds_bytes), s, a);
     return hipGetLastError();
 }
 
@@ -604,13 +610,13 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     ConvPairArgs pa{a, b};
     dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 2);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_bytes, s, pa);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_request(lds_bytes), s, pa);
     return hipGetLastError();
 }
 

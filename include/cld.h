@@ -257,6 +257,10 @@ int cld_profile_read(cld_handle h, double* total_ms /*HOST*/, int64_t* launches 
  * (0..36) of every following U-Net evaluation writes 16 u64 cycle stamps per workgroup into `buf`. */
 int cld_debug_stamps(cld_handle h, void* buf /*DEVICE, u64[16 * workgroups]*/, int32_t layer);
 
+/* Experiments only: every conv launch of this handle asks for at least `bytes` of dynamic LDS (0 = off), which steers how many
+ * workgroups of which stream can share a CU when two handles run on two streams (scripts/exp_streams.py). */
+int cld_debug_lds_floor(cld_handle h, size_t bytes);
+
 /* CLD_PRECISION_* the handle runs with. */
 int cld_get_precision(cld_handle h);
 

@@ -25,8 +25,11 @@ def run_single(B):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
 
-def run_dual(B, nstream=2):
+def run_dual(B, nstream=2, floors=None):
     parts = [mk(B // nstream) for _ in range(nstream)]
+    if floors:      # asymmetric LDS requests: two workgroups of the same stream cannot share a CU, one of each can
+        for (e, *_), f in zip(parts, floors):
+            e.lib.cld_debug_lds_floor(e._h, f)
     streams = [torch.cuda.Stream(dev) for _ in range(nstream)]
     for (e, x, c, z), s in zip(parts, streams):
         with torch.cuda.stream(s): e.sample(x, c, noise=z)
@@ -45,3 +48,6 @@ for B in (Btot // 2, Btot):
 for ns in (2, 4):
     t = run_dual(Btot, ns)
     print(f"{ns} streams x B={Btot//ns}: {t*1e3:.1f} ms  {Btot*100/t:,.0f} step.agent/s")
+for fl in ((100 * 1024, 60 * 1024), (84 * 1024, 76 * 1024), (82 * 1024, 82 * 1024)):
+    t = run_dual(Btot, 2, fl)
+    print(f"2 streams x B={Btot//2}, LDS floors {fl}: {t*1e3:.1f} ms  {Btot*100/t:,.0f} step.agent/s")
