@@ -257,7 +257,8 @@ std::vector<float> pack_conv_weights_split(F&& wget, int c_out, int cin_virtual,
 // wave per SIMD and ~89 % with two (scripts/ubench/mfma_issue.hip), so take the 64-column tile when it still
 // puts two waves on every SIMD of the chip (256 CUs x 4 SIMDs x 2 = 2,048 waves) and the 32-column tile with a
 // 2-way K split (twice the workgroups, two per CU) below that.  Measured at B = 1,024: B 813k vs A 716k
-// step.agent/s; an 8-wave variant (32 columns, 4-way K split) was slower than B and is not built.
+// step.agent/s; an 8-wave variant (32 columns, 4-way K split) was slower than B and is not built; the 8-wave
+// variant C (64 columns, 2-way K split) is taken for the widest layers where it fills the chip (below).
 bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     *g = l.g;
     const long waves_a = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64) * 4;
@@ -265,9 +266,20 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     if (l.g.ain == 1)      // split-precision loop: 64-column tiling only (no K split); 64-channel chunks where the images fit
         return l.has_a ? set(l.g.stride == 2 ? 32 : 64, 4, 1) : false;
     static const char* force = getenv("CLD_TILING");            // experiments only: A / B
+    if (force && force[0] == 'C' && l.c_out == 256 && l.g.ntaps == 5 && l.g.stride == 1) return set(32, 4, 2);   // 8 waves: 64 columns x 2-way K split
     if (force && force[0] == 'A' && l.has_a) return set(32, 4, 1);
     if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
     if (l.has_a && (waves_a >= 2048 || !l.has_b)) return set(32, 4, 1);
+    // tiling C for the 256-channel k5 blocks between 1,024 and 2,047 agents: 8-wave workgroups (64 columns x 2-way K split),
+    // one per CU -- the same two waves per SIMD as B with half the A-image staging per MFMA (+1.4 % end to end at B = 1,024)
+    {
+        ConvGeom c = l.g; c.kc = 32; c.nwn = 4; c.ks = 2;
+        const long wgs_c = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64);
+        static const char* tc = getenv("CLD_TILING_C");       // experiments: "0" = never, "all" = every layer shape that has an instance
+        const bool widest_only = !(tc && tc[0] == 'a');
+        if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c))
+            return set(32, 4, 2);
+    }
     if (l.has_b) return set(32, 2, 2);
     return false;
 }

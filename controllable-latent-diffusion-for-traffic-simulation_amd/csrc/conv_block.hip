@@ -452,7 +452,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     //      partial tile, one barrier, and the epilogue threads add the KS partials while reading ----
     float* O = lds;
     constexpr int OTILE = MT * OP;
-    static_assert(KS * OTILE <= 2 * ABUFP, "partial output tiles must fit in the A images");
+    static_assert((size_t)KS * OTILE * 4 <= 160 * 1024, "partial output tiles must fit in LDS (the launcher sizes the allocation)");
     {
         const int col = nw * 16 + (lane & 15);
         const int rb = 4 * (lane >> 4);
@@ -673,7 +673,8 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
 // (L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT)
 //   tilings: A = (KC 32, NWN 4, KS 1) 64 columns, 4 waves   -- large batches (>= 2 workgroups per CU anyway)
 //            B = (KC 32, NWN 2, KS 2) 32 columns, 4 waves   -- twice the workgroups of A
-//   (the template also supports 8-wave workgroups, e.g. KC 64 / NWN 2 / KS 4; measured slower than B, not built)
+//            C = (KC 32, NWN 4, KS 2) 64 columns, 8 waves   -- the 256-channel k5 blocks at 1,024..2,047 agents (one per CU)
+//   (the template also supports KC 64 / NWN 2 / KS 4; measured slower than B, not built)
 #define CLD_CONV_INSTANCES(X)                            \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
@@ -685,6 +686,9 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
     X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
+    X(13, 13, 1, 5, 32, 4, 2, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
+    X(26, 26, 1, 5, 32, 4, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
+    X(52, 52, 1, 5, 32, 4, 2, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
     X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
     X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
