@@ -278,7 +278,7 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
         static const char* tc = getenv("CLD_TILING_C");       // experiments: "0" = never, "all" = every layer shape that has an instance
         const bool widest_only = !(tc && tc[0] == 'a');
         if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c))
-            return set(32, 4, 2);
+            return set(32, 4, 2);     // (64-channel chunks with this tiling: 918k vs 949k step.agent/s, not built)
     }
     if (l.has_b) return set(32, 2, 2);
     return false;
