@@ -44,7 +44,7 @@ def avg(kernel_sub, counter):
 
 
 out = {}
-dom = "conv_block_kernel<13, 13, 1, 5, 32, 2, 2, 1, 32, 1, 0, 0, 0>"
+dom = "conv_block_kernel<13, 13, 1, 5, 32, 4, 2, 1, 32, 1, 0, 0, 0>"
 fe, wr = avg(dom, "FETCH_SIZE"), avg(dom, "WRITE_SIZE")
 if fe is not None and wr is not None:
     out = {"kernel": "void cld::" + dom + "(cld::ConvArgs)", "batch_agents": 1024,
