@@ -674,7 +674,8 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
 //   tilings: A = (KC 32, NWN 4, KS 1) 64 columns, 4 waves   -- large batches (>= 2 workgroups per CU anyway)
 //            B = (KC 32, NWN 2, KS 2) 32 columns, 4 waves   -- twice the workgroups of A
 //            C = (KC 32, NWN 4, KS 2) 64 columns, 8 waves   -- the 256-channel k5 blocks at 1,024..2,047 agents (one per CU)
-//   (the template also supports KC 64 / NWN 2 / KS 4; measured slower than B, not built)
+//   (the template also supports KC 64 / NWN 2 / KS 4, measured slower than B, and NWN 8 / KS 1 -- 128 columns in an
+//    8-wave workgroup -- measured equal to A at 2,048 and 4,096 agents; neither is built)
 #define CLD_CONV_INSTANCES(X)                            \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
