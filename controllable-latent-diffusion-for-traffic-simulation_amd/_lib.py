@@ -35,7 +35,9 @@ OPTIMIZERS = {"adam": 0, "sgd": 1}
 class CldGuidance(C.Structure):
     """include/cld.h `cld_guidance` (device pointers + optimiser settings of the sampling-time guidance step)."""
     _fields_ = [("curr_states", C.c_void_p), ("target_speed", C.c_void_p), ("loss_scale", C.c_void_p),
-                ("lr", C.c_float), ("perturb_th", C.c_float), ("optimizer", C.c_int32)]
+                ("lr", C.c_float), ("perturb_th", C.c_float), ("optimizer", C.c_int32),
+                ("speed_limit", C.c_float), ("acc_limit", C.c_float),
+                ("speed_limit_scale", C.c_void_p), ("acc_limit_scale", C.c_void_p)]
 
 
 _P = C.c_void_p

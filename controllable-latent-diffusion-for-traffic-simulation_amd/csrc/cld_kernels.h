@@ -166,8 +166,11 @@ struct GuideArgs {
     const float* mean;          // [>=B,52,4] posterior mean of this step
     const float* cond;          // [B,256]
     const float* curr_states;   // [B,4]
-    const float* target_speed;  // [B,52]
+    const float* target_speed;  // [B,52] or null (term off)
     const float* loss_scale;    // [B] or null: d(total loss)/d(sum_t |v_t - target_t|) per agent; null -> 1/52
+    const float* speed_limit_scale;   // [B] or null (term off): weight of sum_t relu(|v_t| - speed_limit)
+    const float* acc_limit_scale;     // [B] or null (term off): weight of sum_t relu(|acc_t| - acc_limit)
+    float speed_limit, acc_limit;
     const float* z;             // [B,52,4] N(0,1) draw or null (on-device generator)
     float* mean_out;            // guided mean [B,52,4] or null
     float* x_out;               // guided mean + sigma z, [>=B,52,4] or null

@@ -25,6 +25,42 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoid_g(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 constexpr int GT = 52;
+// Speed chain + loss gradient of ONE agent (diffuser_helpers.py:573-600 forward; guidance_loss.py losses):
+//   acc_t = act_t * std + mean ; v_t = clip(v_0 + dt * sum_{j<=t} clip(acc_j)) ;
+//   L = s_ts * sum_t |v_t - target_t|              TargetSpeedLoss   :219-254
+//     + s_sl * sum_t relu(|v_t| - speed_limit)      SpeedLimitLoss    :1509-1538
+//     + s_al * sum_t relu(|acc_t| - acc_limit)      AccLimitLoss      :1444-1467 (acts on the unclipped descaled action)
+// act[t * st] in, dact[t] = dL / d act_t out; the clamps pass gradients on [lo, hi] like torch.clamp.
+__device__ __forceinline__ void speed_chain_grad(const DynParams& d, const GuideArgs& a, int b, const float* act, int st, float* dact) {
+    const float* cs = a.curr_states + (size_t)b * 4;
+    const float* tgt = a.target_speed ? a.target_speed + (size_t)b * GT : nullptr;
+    const float s_ts = tgt ? (a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT)) : 0.f;
+    const float s_sl = a.speed_limit_scale ? a.speed_limit_scale[b] : 0.f;
+    const float s_al = a.acc_limit_scale ? a.acc_limit_scale[b] : 0.f;
+    float v_raw = cs[2];
+    for (int t = 0; t < GT; ++t) {
+        const float acc = act[t * st] * d.std[4] + d.mean[4];
+        v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
+        const bool vok = v_raw >= d.v_lo && v_raw <= d.v_hi;
+        const float v = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
+        float gvt = 0.f;
+        if (tgt) {
+            const float df = v - tgt[t];
+            gvt += s_ts * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));      // d|x|/dx, 0 at 0 (and for NaN targets: nan_to_num)
+        }
+        if (s_sl != 0.f && fabsf(v) - a.speed_limit > 0.f) gvt += s_sl * ((v > 0.f) ? 1.f : -1.f);
+        dact[t] = vok ? gvt : 0.f;                                        // dL/dv_t for now
+    }
+    float run = 0.f;
+    for (int t = GT - 1; t >= 0; --t) {                                          // v_k depends on every acc_j, j <= k
+        run += dact[t];
+        const float acc = act[t * st] * d.std[4] + d.mean[4];
+        float g = (acc >= d.acc_lo && acc <= d.acc_hi) ? run * d.dt : 0.f;
+        if (s_al != 0.f && fabsf(acc) - a.acc_limit > 0.f) g += s_al * ((acc > 0.f) ? 1.f : -1.f);
+        dact[t] = g * d.std[4];
+    }
+}
+
 constexpr int G_GATES = GT * 2 * 256;        // floats: post-activation gates [t][layer][256]
 constexpr int G_CELLS = GT * 2 * 64;         // floats: cell states [t][layer][64]
 constexpr int GNA = 2;                       // agents per workgroup: the register-resident weights are reused across them
@@ -158,28 +194,7 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
         }
         __syncthreads();
         // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
-        if (r < NA) {
-            const int b = agent(r);
-            const float* cs = a.curr_states + (size_t)b * 4;
-            const float* tgt = a.target_speed + (size_t)b * GT;
-            const float scale = a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT);
-            float v_raw = cs[2];
-            for (int t = 0; t < GT; ++t) {
-                const float acc = act[r][t] * d.std[4] + d.mean[4];
-                v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
-                const bool vok = v_raw >= d.v_lo && v_raw <= d.v_hi;         // clamp passes the gradient on [lo, hi]
-                const float v = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
-                const float df = v - tgt[t];
-                const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);   // d|x|/dx, 0 at 0 (and for NaN targets: nan_to_num)
-                dact[r][t] = vok ? scale * sgn : 0.f;                        // dL/dv_t for now
-            }
-            float run = 0.f;
-            for (int t = GT - 1; t >= 0; --t) {                               // v_k depends on every acc_j, j <= k
-                run += dact[r][t];
-                const float acc = act[r][t] * d.std[4] + d.mean[4];
-                dact[r][t] = (acc >= d.acc_lo && acc <= d.acc_hi) ? run * d.dt * d.std[4] : 0.f;
-            }
-        }
+        if (r < NA) speed_chain_grad(d, a, agent(r), &act[r][0], 1, &dact[r][0]);
         for (int ag = pt; ag < NA; ag += 4) { rec1[ag][j] = 0.f; rec0[ag][j] = 0.f; dc1n[ag][j] = 0.f; dc0n[ag][j] = 0.f; }
         __syncthreads();
         // ---------------- backward through time: thread (unit j, agent pt) owns one cell ----------------
@@ -474,28 +489,8 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
         }
         // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
         if (tid < AG) {
-            const int b = agent(tid);
-            const float* cs = a.curr_states + (size_t)b * 4;
-            const float* tgt = a.target_speed + (size_t)b * GT;
-            const float scale = a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT);
-            float v_raw = cs[2];
-            for (int t = 0; t < GT; ++t) {
-                const float as = actp[t][0][tid] + actp[t][1][tid] + actp[t][2][tid] + actp[t][3][tid] + bh2a;
-                actp[t][0][tid] = as;
-                const float acc = as * d.std[4] + d.mean[4];
-                v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
-                const bool vok = v_raw >= d.v_lo && v_raw <= d.v_hi;
-                const float v = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
-                const float df = v - tgt[t];
-                const float sgn = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-                dact[tid][t] = vok ? scale * sgn : 0.f;
-            }
-            float run = 0.f;
-            for (int t = GT - 1; t >= 0; --t) {
-                run += dact[tid][t];
-                const float acc = actp[t][0][tid] * d.std[4] + d.mean[4];
-                dact[tid][t] = (acc >= d.acc_lo && acc <= d.acc_hi) ? run * d.dt * d.std[4] : 0.f;
-            }
+            for (int t = 0; t < GT; ++t) actp[t][0][tid] = actp[t][0][tid] + actp[t][1][tid] + actp[t][2][tid] + actp[t][3][tid] + bh2a;
+            speed_chain_grad(d, a, agent(tid), &actp[0][0][tid], 4 * AG, &dact[tid][0]);
         }
         __syncthreads();
         // ---------------- backward through time ----------------

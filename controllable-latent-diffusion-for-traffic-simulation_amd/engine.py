@@ -141,19 +141,33 @@ class Engine:
         return xn, mean, float(sigma.value)
 
     def _guidance(self, g: Mapping, B: int):
-        """dict(curr_states [B,4], target_speed [B,52], loss_scale [B] | None, lr | None, perturb_th | None | "sigma",
-        optimizer "adam" | "sgd") -> (CldGuidance, tensors kept alive).  lr None = sigma_t; perturb_th None = no clip (what
+        """dict(curr_states [B,4], target_speed [B,52] | None, loss_scale [B] | None, speed_limit (limit, scale) | None,
+        acc_limit (limit, scale) | None, lr | None, perturb_th | None | "sigma", optimizer "adam" | "sgd")
+        -> (CldGuidance, tensors kept alive).  A `scale` is a per-agent tensor [B] (weight / (agents of the scene * 52),
+        as DiffuserGuidance averages) or a scalar weight (divided by 52 here).  lr None = sigma_t; perturb_th None = no clip (what
         the reference's perturb() does), "sigma" = clip to sigma_t, a number = clip to it (include/cld.h)."""
-        cs = self._f32(g["curr_states"], (B, 4)); ts = self._f32(g["target_speed"], (B, T))
+        cs = self._f32(g["curr_states"], (B, 4))
+        ts = None if g.get("target_speed") is None else self._f32(g["target_speed"], (B, T))
         ls = None if g.get("loss_scale") is None else self._f32(g["loss_scale"], (B,))
+        # optional SpeedLimitLoss / AccLimitLoss terms: (limit, per-agent scale [B] or a scalar weight)
+        def term(key):
+            v = g.get(key)
+            if v is None:
+                return 0.0, None
+            lim, sc = v
+            sc = torch.full((B,), float(sc) / T, device=self.device) if not isinstance(sc, torch.Tensor) and np.isscalar(sc) else self._f32(sc, (B,))
+            return float(lim), sc
+        sl, sls = term("speed_limit")
+        al, als = term("acc_limit")
         th = g.get("perturb_th")
         opt = g.get("optimizer", "adam")
         if opt not in _lib.OPTIMIZERS:
             raise CldError(f"unknown guidance optimizer '{opt}' (adam | sgd)")
-        cg = _lib.CldGuidance(cs.data_ptr(), ts.data_ptr(), None if ls is None else ls.data_ptr(),
+        cg = _lib.CldGuidance(cs.data_ptr(), None if ts is None else ts.data_ptr(), None if ls is None else ls.data_ptr(),
                               float(g["lr"]) if g.get("lr") else 0.0,
-                              -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt])
-        return cg, (cs, ts, ls)
+                              -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
+                              sl, al, None if sls is None else sls.data_ptr(), None if als is None else als.data_ptr())
+        return cg, (cs, ts, ls, sls, als)
 
     def guidance_step(self, mean, cond, guidance: Mapping, sigma: float, z=None, want_grad=False):
         """One guidance step on a posterior mean [B,52,4] (upstream PerturbationGuidance.perturb, guidance_loss.py:2221-2282)

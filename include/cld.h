@@ -144,6 +144,7 @@ int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const flo
  * at every step t > 0 the posterior mean mu is decoded to a trajectory, the guidance loss
  *     L = sum_agents loss_scale[b] * sum_t |v_t - target_speed[b,t]|         (TargetSpeedLoss, guidance_loss.py:219-254;
  *         loss_scale[b] = weight / (agents guided in b's scene * 52) reproduces DiffuserGuidance.compute_guidance_loss :2143-2175)
+ *       [+ SpeedLimitLoss and AccLimitLoss terms, see the struct; any combination, as upstream sums its configured losses]
  * is differentiated through the roll-out and the decoder down to mu, ONE optimiser step is taken on mu
  * (Adam's first step: delta = -lr * g / (|g| + 1e-8); SGD: delta = -lr * g; scene_edit_config.py:74-90 defaults adam,
  * lr 0.3, grad_steps 1), and x_{t-1} = mu + delta + sigma_t z.  Step t = 0 is not guided (apply_guidance_output = False).
@@ -154,11 +155,19 @@ int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const flo
 enum { CLD_GUIDE_ADAM = 0, CLD_GUIDE_SGD = 1 };
 typedef struct cld_guidance {
     const float* curr_states;   /* [B,4]  (x, y, v, yaw) the roll-out starts from                        */
-    const float* target_speed;  /* [B,52] m/s                                                             */
-    const float* loss_scale;    /* [B] or NULL (= 1/52 per agent)                                         */
+    const float* target_speed;  /* [B,52] m/s, or NULL: no target-speed term                              */
+    const float* loss_scale;    /* [B] or NULL (= 1/52 per agent): weight of the target-speed term        */
     float lr;                   /* <= 0: sigma_t  (upstream: `if lr is None: lr = sigma`, diffuser.py:899) */
     float perturb_th;           /* < 0: no clip (reference behaviour) ; 0: sigma_t ; > 0: that threshold    */
     int32_t optimizer;          /* CLD_GUIDE_ADAM | CLD_GUIDE_SGD                                          */
+    /* two more losses on the same speed chain, each off when its scale pointer is NULL:
+     *   SpeedLimitLoss (guidance_loss.py:1509-1538): sum_b speed_limit_scale[b] * sum_t relu(|v_t| - speed_limit)
+     *   AccLimitLoss   (guidance_loss.py:1444-1467): sum_b acc_limit_scale[b]   * sum_t relu(|acc_t| - acc_limit), on the
+     *                  descaled, unclipped acceleration channel of the decoded trajectory                            */
+    float speed_limit;                 /* m/s   */
+    float acc_limit;                   /* m/s^2 */
+    const float* speed_limit_scale;    /* [B] or NULL */
+    const float* acc_limit_scale;      /* [B] or NULL */
 } cld_guidance;
 
 /* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */

@@ -412,10 +412,11 @@ def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, tap
 # --------------------------------------------------------------------------- #
 # f-3  sampling-time guidance (upstream diffuser.py:844-929, guidance_loss.py:219-254,2221-2282)
 # --------------------------------------------------------------------------- #
-def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor, loss_scale: Optional[Tensor],
-                  lr: float, perturb_th: Optional[float], optimizer: str = "adam"):
+def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Optional[Tensor], loss_scale: Optional[Tensor],
+                  lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None):
     """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282, grad_steps = 1) with decoder = `decode` and
-    TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target|; Adam's first step is
+    TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target| (+ optional SpeedLimitLoss / AccLimitLoss
+    terms, each a (limit, per-agent scale) pair); Adam's first step is
     -lr * g / (|g| + 1e-8) (bias-corrected moments of a single gradient), SGD's -lr * g.  perturb_th None = the
     reference's actual behaviour: its clip (:2275-2278) acts on x_guidance - x_initial, two names of one tensor
     (:2239), so it never changes anything (the golden vectors confirm); a number clips the step as the code intends.
@@ -423,9 +424,15 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Te
     x = mean.clone().requires_grad_(True)
     with torch.enable_grad():
         traj = decode(wdec, x, cond, cs, True)
-        dev = (traj[..., 2] - target_speed).abs()
-        sc = loss_scale if loss_scale is not None else torch.full((mean.shape[0],), 1.0 / mean.shape[1], dtype=mean.dtype)
-        loss = (dev.sum(dim=1) * sc).sum()
+        loss = traj.sum() * 0.0
+        if target_speed is not None:
+            dev = (traj[..., 2] - target_speed).abs()
+            sc = loss_scale if loss_scale is not None else torch.full((mean.shape[0],), 1.0 / mean.shape[1], dtype=mean.dtype)
+            loss = loss + (dev.sum(dim=1) * sc).sum()
+        if speed_limit is not None:        # (limit, scale [B]): SpeedLimitLoss, guidance_loss.py:1509-1538
+            loss = loss + ((traj[..., 2].abs() - speed_limit[0]).clamp(min=0).sum(dim=1) * speed_limit[1]).sum()
+        if acc_limit is not None:          # (limit, scale [B]): AccLimitLoss, guidance_loss.py:1444-1467
+            loss = loss + ((traj[..., 4].abs() - acc_limit[0]).clamp(min=0).sum(dim=1) * acc_limit[1]).sum()
         (g,) = torch.autograd.grad(loss, x)
     delta = -lr * g / (g.abs() + 1e-8) if optimizer == "adam" else -lr * g
     if perturb_th is not None:

@@ -204,9 +204,21 @@ def section_guidance(ref):
         xg, _ = pg.perturb(x_init, {"scene_index": scene_index}, {"optimizer": opt_name, "lr": lr, "grad_steps": 1, "perturb_th": th},
                            num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
         out[f"guided_{opt_name}"] = xg.detach()
+    # three losses summed in scene 0 (target speed 1.0, speed limit 0.5, acceleration limit 4.0), speed limit alone (3.0) in scene 1
+    combo = [[{"name": "target_speed", "weight": 1.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None},
+              {"name": "speed_limit", "weight": 0.5, "params": {"speed_limit": 6.0}, "agents": None},
+              {"name": "acc_limit", "weight": 4.0, "params": {"acc_limit": 0.1}, "agents": None}],
+             [{"name": "speed_limit", "weight": 3.0, "params": {"speed_limit": 6.0}, "agents": None}]]
+    pg = gl.PerturbationGuidance(transform=lambda x, data_batch, params, bsize, num_samp: x, transform_params=None)
+    pg.set_guidance(combo)
+    xg, _ = pg.perturb(mean.clone(), {"scene_index": scene_index}, {"optimizer": "sgd", "lr": 5.0, "grad_steps": 1, "perturb_th": None},
+                       num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
+    out["guided_combo_sgd"] = xg.detach()
     save("guidance", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "mean": "normal(in_seed,'guide_mean')",
                       "target_speed": "uniform(in_seed,'guide_target_speed',0,12)", "scenes": [3, 5], "weights": [1.0, 2.0],
                       "adam": {"lr": 0.3, "perturb_th": 0.2}, "sgd": {"lr": 5.0, "perturb_th": 0.5},
+                      "combo_sgd": {"lr": 5.0, "scene0": {"target_speed": 1.0, "speed_limit": [6.0, 0.5], "acc_limit": [0.1, 4.0]},
+                                    "scene1": {"speed_limit": [6.0, 3.0]}},
                       "decoder": "oracle.decode (pinned by decode.npz)"}, **out)
 
 

@@ -430,3 +430,30 @@ def test_vae_forward_reconstruction_path():
     ref = O.decode(w, z, cond, cs, descaled_output=True)
     assert (out["mu"].cpu() - mu).abs().max().item() <= 5e-5 and (out["logvar"].cpu() - lv).abs().max().item() <= 5e-5
     assert (out["output"].cpu() - ref[..., :2]).abs().max().item() <= 2e-4 * max(1.0, ref[..., :2].abs().max().item())
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
+    """Target-speed + speed-limit + acceleration-limit guidance in one step against the reference's own perturb() (golden
+    'guidance', combo_sgd), through both formulations of the guidance kernel."""
+    import os
+    meta, g = golden("guidance")
+    cond, cs, mean, tgt, _ = _guidance_inputs(meta)
+    c = meta["combo_sgd"]
+    n0, n1 = meta["scenes"]
+    ts = torch.tensor([c["scene0"]["target_speed"] / (n0 * 52)] * n0 + [0.0] * n1)
+    sl = torch.tensor([c["scene0"]["speed_limit"][1] / (n0 * 52)] * n0 + [c["scene1"]["speed_limit"][1] / (n1 * 52)] * n1)
+    al = torch.tensor([c["scene0"]["acc_limit"][1] / (n0 * 52)] * n0 + [0.0] * n1)
+    gd = {"curr_states": cs, "target_speed": tgt, "loss_scale": ts, "speed_limit": (c["scene0"]["speed_limit"][0], sl),
+          "acc_limit": (c["scene0"]["acc_limit"][0], al), "lr": c["lr"], "perturb_th": None, "optimizer": "sgd"}
+    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    try:
+        mg = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["CLD_GUIDE_KERNEL"]
+    step = np.abs(g["guided_combo_sgd"] - mean.numpy()).max()
+    assert np.abs(mg.cpu().numpy() - g["guided_combo_sgd"]).max() <= max(3e-5 * step, 2.5e-7)
+    # a speed limit alone (no target-speed term) is accepted too
+    only = eng_jitter.guidance_step(mean, cond, {"curr_states": cs, "speed_limit": (6.0, 1.0), "lr": 1.0, "optimizer": "sgd"}, sigma=0.5)
+    assert bool(torch.isfinite(only).all())

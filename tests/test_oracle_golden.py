@@ -219,3 +219,20 @@ def test_reward_helpers_vs_reference(golden):
     assert np.array_equal((off < 0).float().numpy(), g["any_offroad"])
     assert abs(float((off < 0).float().mean()) - meta["rates"]["offroad_failure_rate"]) < 1e-6
     assert abs(float((col < 0).float().mean()) - meta["rates"]["collision_failure_rate"]) < 1e-6
+
+
+def test_guidance_combined_losses_vs_reference_perturb(golden):
+    """Three upstream losses summed by DiffuserGuidance in one scene (target speed + SpeedLimitLoss + AccLimitLoss) and a
+    speed limit alone in the other, through the reference's own perturb() (SGD): pins the two extra loss terms."""
+    meta, g = golden("guidance")
+    cond, cs, mean, tgt, _ = _guidance_inputs(meta)
+    c = meta["combo_sgd"]
+    n0, n1 = meta["scenes"]
+    ts = torch.tensor([c["scene0"]["target_speed"] / (n0 * 52)] * n0 + [0.0] * n1)
+    sl = torch.tensor([c["scene0"]["speed_limit"][1] / (n0 * 52)] * n0 + [c["scene1"]["speed_limit"][1] / (n1 * 52)] * n1)
+    al = torch.tensor([c["scene0"]["acc_limit"][1] / (n0 * 52)] * n0 + [0.0] * n1)
+    wdec = O.to_torch(synth.make_decoder_weights(meta["w_seed"]))
+    xg, _ = O.guidance_step(wdec, mean, cond, cs, tgt, ts, c["lr"], None, "sgd", speed_limit=(c["scene0"]["speed_limit"][0], sl),
+                            acc_limit=(c["scene0"]["acc_limit"][0], al))
+    assert np.abs(xg.numpy() - g["guided_combo_sgd"]).max() <= 2e-6
+    assert np.abs(g["guided_combo_sgd"] - g["guided_sgd"]).max() > 1e-3          # the extra terms do change the step
