@@ -37,7 +37,8 @@ class CldGuidance(C.Structure):
     _fields_ = [("curr_states", C.c_void_p), ("target_speed", C.c_void_p), ("loss_scale", C.c_void_p),
                 ("lr", C.c_float), ("perturb_th", C.c_float), ("optimizer", C.c_int32),
                 ("speed_limit", C.c_float), ("acc_limit", C.c_float),
-                ("speed_limit_scale", C.c_void_p), ("acc_limit_scale", C.c_void_p)]
+                ("speed_limit_scale", C.c_void_p), ("acc_limit_scale", C.c_void_p),
+                ("target_pos", C.c_void_p), ("target_time", C.c_void_p), ("target_pos_scale", C.c_void_p)]
 
 
 _P = C.c_void_p

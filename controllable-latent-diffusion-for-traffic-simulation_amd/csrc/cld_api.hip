@@ -914,9 +914,10 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal n_timesteps (the reference sampler has stride 1)");
     if (gd) {
         if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
-        if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale))
+        if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale))
             return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
         if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
+        if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, std::string(fn) + ": target_pos_scale needs target_pos and target_time");
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     // CFG: one 2B-agent batch per step: rows [0, bp) carry cond_feat, rows [bp, 2bp) the unconditional features,
@@ -956,6 +957,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
             g.loss_scale = gd->loss_scale; g.z = a.z; g.x_out = w.xw; g.x_out2 = cfg ? x_hi : nullptr;
             g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
             g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
+            g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
             g.scratch = w.guide; g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
             g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
             HIPCK(h, launch_guide(h->dec, h->dyn, g, s));
@@ -991,15 +993,17 @@ int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const 
     int rc = check_common(h, "cld_guidance_step", B, 0, workspace, workspace_bytes);
     if (rc) return rc;
     if (!h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_guidance_step: decoder weights not loaded");
-    if (!mean || !cond || !gd || !gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale) ||
+    if (!mean || !cond || !gd || !gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale) ||
         (x_next && sigma != 0.f && !z))
         return fail(h, CLD_ERR_ARG, "cld_guidance_step: null pointer");
     if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, "cld_guidance_step: unknown optimizer");
+    if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, "cld_guidance_step: target_pos_scale needs target_pos and target_time");
     Ws w = carve(workspace, pad16(B));
     GuideArgs g{};
     g.mean = mean; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed; g.loss_scale = gd->loss_scale;
     g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
     g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
+    g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
     g.z = z; g.mean_out = mean_guided; g.x_out = x_next; g.grad_out = grad; g.scratch = w.guide;
     g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
     g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B;

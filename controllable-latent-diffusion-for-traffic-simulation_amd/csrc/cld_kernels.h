@@ -171,6 +171,9 @@ struct GuideArgs {
     const float* speed_limit_scale;   // [B] or null (term off): weight of sum_t relu(|v_t| - speed_limit)
     const float* acc_limit_scale;     // [B] or null (term off): weight of sum_t relu(|acc_t| - acc_limit)
     float speed_limit, acc_limit;
+    const float* target_pos;          // [B,2] waypoint in the agent frame, or null
+    const int* target_time;           // [B] index (0..51) of the trajectory state that should hit it
+    const float* target_pos_scale;    // [B] or null (term off): weight of |pos[target_time] - target_pos|
     const float* z;             // [B,52,4] N(0,1) draw or null (on-device generator)
     float* mean_out;            // guided mean [B,52,4] or null
     float* x_out;               // guided mean + sigma z, [>=B,52,4] or null

@@ -25,39 +25,108 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sigmoid_g(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 constexpr int GT = 52;
-// Speed chain + loss gradient of ONE agent (diffuser_helpers.py:573-600 forward; guidance_loss.py losses):
-//   acc_t = act_t * std + mean ; v_t = clip(v_0 + dt * sum_{j<=t} clip(acc_j)) ;
-//   L = s_ts * sum_t |v_t - target_t|              TargetSpeedLoss   :219-254
-//     + s_sl * sum_t relu(|v_t| - speed_limit)      SpeedLimitLoss    :1509-1538
-//     + s_al * sum_t relu(|acc_t| - acc_limit)      AccLimitLoss      :1444-1467 (acts on the unclipped descaled action)
-// act[t * st] in, dact[t] = dL / d act_t out; the clamps pass gradients on [lo, hi] like torch.clamp.
-__device__ __forceinline__ void speed_chain_grad(const DynParams& d, const GuideArgs& a, int b, const float* act, int st, float* dact) {
+// Unicycle roll-out + loss gradient of ONE agent (forward: diffuser_helpers.py:541-639 'parallel'; losses: guidance_loss.py):
+//   acc_t = act0_t * std4 + mean4 ; w_t = act1_t * std5 + mean5
+//   v_k   = clip(v_0 + dt * sum_{j<k} clip(acc_j)), k = 0..52 ; vbar_k = (v_k + v_{k+1}) / 2
+//   yb_k  = max(min(0.5 |v_k|, max_yawvel / max(|v_k|, 0.1)), 0.1) ; wc_k = clip(w_k, +-yb_k)
+//   th_k  = yaw_0 + dt * sum_{j<k} wc_j ; x_{k+1} = x_0 + dt * sum_{j<=k} vbar_j cos th_j (y: sin)
+//   L = s_ts * sum_t |v_{t+1} - target_t|                       TargetSpeedLoss      :219-254
+//     + s_sl * sum_t relu(|v_{t+1}| - speed_limit)               SpeedLimitLoss       :1509-1538
+//     + s_al * sum_t relu(|acc_t| - acc_limit)                   AccLimitLoss         :1444-1467 (unclipped descaled action)
+//     + s_tp * |(x, y)_{T*+1} - target_pos|                      TargetPosAtTimeLoss  :632-670
+// act0 / act1 [t * st] in; dact0 / dact1 [t] = dL / d act out.  min / max / clamp pass gradients like torch (clamp: on
+// [lo, hi]; an active bound of the yaw-rate clip routes the gradient into yb and from there into v_k).
+// sc: 4 x 54 floats of per-agent scratch (v_k, th_k, dL/dv_k, dL/dth_k).
+__device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& a, int b, const float* act0, const float* act1, int st,
+                                           float* dact0, float* dact1, float* sc) {
+    float* vk = sc; float* th = sc + 54; float* gv = sc + 108; float* gth = sc + 162;   // gth: clip mask of v_k (1 = inside the bounds)
     const float* cs = a.curr_states + (size_t)b * 4;
     const float* tgt = a.target_speed ? a.target_speed + (size_t)b * GT : nullptr;
     const float s_ts = tgt ? (a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT)) : 0.f;
     const float s_sl = a.speed_limit_scale ? a.speed_limit_scale[b] : 0.f;
     const float s_al = a.acc_limit_scale ? a.acc_limit_scale[b] : 0.f;
-    float v_raw = cs[2];
+    const float s_tp = a.target_pos_scale ? a.target_pos_scale[b] : 0.f;
+    const bool pos = s_tp != 0.f;
+    // ---- forward ----
+    float v_raw = cs[2], x = cs[0], y = cs[1], yaw = cs[3];
+    vk[0] = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
+    th[0] = yaw;
+    gv[0] = 0.f;
+    int tstar = 0;
+    float px = 0.f, py = 0.f;
+    if (pos) { tstar = a.target_time[b]; tstar = tstar < 0 ? 0 : (tstar > GT - 1 ? GT - 1 : tstar); }
     for (int t = 0; t < GT; ++t) {
-        const float acc = act[t * st] * d.std[4] + d.mean[4];
+        const float acc = act0[t * st] * d.std[4] + d.mean[4];
         v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
         const bool vok = v_raw >= d.v_lo && v_raw <= d.v_hi;
         const float v = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
-        float gvt = 0.f;
+        vk[t + 1] = v;
+        float g = 0.f;
         if (tgt) {
             const float df = v - tgt[t];
-            gvt += s_ts * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));      // d|x|/dx, 0 at 0 (and for NaN targets: nan_to_num)
+            g += s_ts * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));        // d|x|/dx, 0 at 0 (and for NaN targets: nan_to_num)
         }
-        if (s_sl != 0.f && fabsf(v) - a.speed_limit > 0.f) gvt += s_sl * ((v > 0.f) ? 1.f : -1.f);
-        dact[t] = vok ? gvt : 0.f;                                        // dL/dv_t for now
+        if (s_sl != 0.f && fabsf(v) - a.speed_limit > 0.f) g += s_sl * ((v > 0.f) ? 1.f : -1.f);
+        gv[t + 1] = g;                          // direct loss terms on v_{t+1}; the clip mask is applied in the backward sweep
+        gth[t + 1] = vok ? 1.f : 0.f;           // (borrowed until the backward sweep: clip mask of v_{t+1})
+        if (pos) {
+            const float av = fabsf(vk[t]);
+            const float yb = fmaxf(fminf(d.max_steer * av, d.max_yawvel / fmaxf(av, 0.1f)), 0.1f);
+            const float wr = act1[t * st] * d.std[5] + d.mean[5];
+            const float wc = fmaxf(fminf(wr, yb), -yb);
+            const float vbar = 0.5f * (vk[t] + v);
+            x += vbar * cosf(yaw) * d.dt;
+            y += vbar * sinf(yaw) * d.dt;
+            yaw += wc * d.dt;
+            th[t + 1] = yaw;
+            if (t == tstar) { px = x; py = y; }
+        }
     }
-    float run = 0.f;
-    for (int t = GT - 1; t >= 0; --t) {                                          // v_k depends on every acc_j, j <= k
-        run += dact[t];
-        const float acc = act[t * st] * d.std[4] + d.mean[4];
-        float g = (acc >= d.acc_lo && acc <= d.acc_hi) ? run * d.dt : 0.f;
+    // ---- backward ----
+    float gx = 0.f, gy = 0.f;                   // dL/dx_{k+1}, dL/dy_{k+1} summed over k >= current step (suffix sums)
+    float tx = 0.f, ty = 0.f;
+    if (pos) {
+        const float ex = px - a.target_pos[2 * b], ey = py - a.target_pos[2 * b + 1];
+        const float nrm = sqrtf(ex * ex + ey * ey);
+        if (nrm > 0.f) { tx = s_tp * ex / nrm; ty = s_tp * ey / nrm; }          // d|e|/de (torch.norm: 0 at 0)
+    }
+    float g_th_suffix = 0.f;                    // sum_{m > k} dL/dth_m
+    float run_v = 0.f;                          // sum_{k > j} dL/dv_raw_k
+    float d_vbar_next = 0.f;                    // dL/dvbar_{k+1}
+    for (int k = GT - 1; k >= 0; --k) {
+        float d_w = 0.f, d_vk_from_yb = 0.f, d_vbar = 0.f;
+        if (pos) {
+            if (k == tstar) { gx += tx; gy += ty; }
+            float sn, cn;
+            sincosf(th[k], &sn, &cn);
+            const float vbar = 0.5f * (vk[k] + vk[k + 1]);
+            d_vbar = d.dt * (gx * cn + gy * sn);
+            const float d_thk = d.dt * vbar * (-gx * sn + gy * cn);              // dL/dth_k through the positions
+            // th_m for m > k depends on wc_k
+            const float d_wc = d.dt * g_th_suffix;
+            const float av = fabsf(vk[k]);
+            const float ya = d.max_steer * av, ybb = d.max_yawvel / fmaxf(av, 0.1f);
+            const float yb = fmaxf(fminf(ya, ybb), 0.1f);
+            const float wr = act1[k * st] * d.std[5] + d.mean[5];
+            float d_yb = 0.f;
+            if (wr > yb) d_yb = d_wc; else if (wr < -yb) d_yb = -d_wc; else d_w = d_wc;
+            if (d_yb != 0.f && fminf(ya, ybb) > 0.1f) {                           // the 0.1 floor is not active
+                const float dyb_dav = (ya < ybb) ? d.max_steer : ((av > 0.1f) ? -d.max_yawvel / (av * av) : 0.f);
+                d_vk_from_yb = d_yb * dyb_dav * ((vk[k] > 0.f) ? 1.f : ((vk[k] < 0.f) ? -1.f : 0.f));
+            }
+            g_th_suffix += d_thk;               // th_k joins the suffix for steps below k
+        }
+        // v_{k+1}: direct terms + both averages it enters (vbar_k and vbar_{k+1})
+        const float d_vk1 = (gv[k + 1] + 0.5f * (d_vbar + d_vbar_next)) * gth[k + 1];      // gth: clip mask of v_{k+1}
+        // (the yaw-bound path of v_{k+1}, as v_prev of step k+1, was added into gv[k+1] by the iteration above)
+        run_v += d_vk1;
+        const float acc = act0[k * st] * d.std[4] + d.mean[4];
+        float g = (acc >= d.acc_lo && acc <= d.acc_hi) ? run_v * d.dt : 0.f;
         if (s_al != 0.f && fabsf(acc) - a.acc_limit > 0.f) g += s_al * ((acc > 0.f) ? 1.f : -1.f);
-        dact[t] = g * d.std[4];
+        dact0[k] = g * d.std[4];
+        dact1[k] = d_w * d.std[5];
+        gv[k] += d_vk_from_yb;                  // v_k is v_prev of step k (k >= 1: a parameter-dependent speed)
+        d_vbar_next = d_vbar;
     }
 }
 
@@ -94,8 +163,9 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
     constexpr int NA = GNA;
     __shared__ __attribute__((aligned(16))) float h0[NA][64], h1[NA][64], c0[NA][64], c1[NA][64], gates[NA][256], zin[NA][208];
     __shared__ __attribute__((aligned(16))) float condm[NA][256];
-    __shared__ float act[NA][GT];            // scaled acceleration output of the decoder
-    __shared__ float dact[NA][GT];           // dL / d(scaled acceleration output)
+    __shared__ float act[NA][2][GT];         // scaled (acceleration, yaw-rate) output of the decoder
+    __shared__ float dact[NA][2][GT];        // dL / d(scaled output)
+    __shared__ float chs[NA][216];           // roll-out scratch of chain_grad
     __shared__ __attribute__((aligned(16))) float dgl[NA][256];           // gate gradients of the layer being processed
     __shared__ float part[3][NA][4][64];     // partial transposed products
     __shared__ float rec1[NA][64], rec0[NA][64], dh0l1[NA][64], dc1n[NA][64], dc0n[NA][64];
@@ -105,8 +175,8 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
     const int j = r & 63, pt = r >> 6;       // matvec phases: (column, row block); per-cell phases: unit j of agents pt, pt + 4, ...
 
     const float bias0 = w.b0[r], bias1 = w.b1[r];
-    const float wa0 = w.w_h2a[j];                            // d act[:, 0] / d h1[j]
-    const float bh2a = w.b_h2a[0];
+    const float wa0 = w.w_h2a[j], wa1 = w.w_h2a[64 + j];     // d act[:, c] / d h1[j]
+    const float bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
 
     const int ngroups = (a.B + NA - 1) / NA;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -184,17 +254,17 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
                 h1[ag][j] = gates[ag][192 + j] * tanhf(c);
             }
             __syncthreads();
-            for (int ag = pt; ag < NA; ag += 4) {   // hid2act, acceleration channel only (the speed loss does not see the yaw
-                float s = h1[ag][j] * wa0;          // rate): one wave per agent, lane j holds unit j
+            for (int ag = pt; ag < NA; ag += 4) {   // hid2act: one wave per agent, lane j holds unit j
+                float s0 = h1[ag][j] * wa0, s1 = h1[ag][j] * wa1;
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-                if (j == 0) act[ag][t] = s + bh2a;
+                for (int o = 32; o >= 1; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+                if (j == 0) { act[ag][0][t] = s0 + bh2a; act[ag][1][t] = s1 + bh2b; }
             }
         }
         }
         __syncthreads();
         // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
-        if (r < NA) speed_chain_grad(d, a, agent(r), &act[r][0], 1, &dact[r][0]);
+        if (r < NA) chain_grad(d, a, agent(r), &act[r][0][0], &act[r][1][0], 1, &dact[r][0][0], &dact[r][1][0], &chs[r][0]);
         for (int ag = pt; ag < NA; ag += 4) { rec1[ag][j] = 0.f; rec0[ag][j] = 0.f; dc1n[ag][j] = 0.f; dc0n[ag][j] = 0.f; }
         __syncthreads();
         // ---------------- backward through time: thread (unit j, agent pt) owns one cell ----------------
@@ -246,7 +316,7 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
                     const float ig = cg[q][1][0], fg = cg[q][1][1], gg = cg[q][1][2], og = cg[q][1][3];
                     const float c = cc[q][1], cp = ccp[q][1];
                     const float tc = tanhf(c);
-                    const float dh = wa0 * dact[ag][t] + rec1[ag][j];
+                    const float dh = wa0 * dact[ag][0][t] + wa1 * dact[ag][1][t] + rec1[ag][j];
                     const float dc = dh * og * (1.f - tc * tc) + dc1n[ag][j];
                     dgl[ag][j] = dc * gg * ig * (1.f - ig);
                     dgl[ag][64 + j] = dc * cp * fg * (1.f - fg);
@@ -365,15 +435,16 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
     __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
     __shared__ __attribute__((aligned(16))) float zin[AG][208];
     __shared__ __attribute__((aligned(16))) float condm[AG][256];
-    __shared__ float actp[GT][4][AG];        // per-wave partials of the acceleration output
-    __shared__ float dact[AG][GT];
+    __shared__ float actp[2][GT][4][AG];     // per-wave partials of the (acceleration, yaw-rate) output
+    __shared__ float dact[AG][2][GT];
+    __shared__ float chs[AG][216];           // roll-out scratch of chain_grad
     __shared__ float dzp[2][4][AG][4];       // per-wave partials of dL/dz_t, by step parity
     __shared__ float dz[AG][208];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, rb = lane >> 4;        // MFMA layouts: A lane = (row n, k kk = rb); B lane = (col n, k rb); D lane = (col n, rows 4rb..4rb+3)
     const int u = 16 * wv + n;                      // this lane's hidden unit
-    const float wa0 = w.w_h2a[u], bh2a = w.b_h2a[0];
+    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
 
     const int ngroups = (a.B + AG - 1) / AG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -464,7 +535,7 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
                         }
                 }
                 kp += 5 * 4 * 256;
-                float ap[4];
+                float ap[4], aq[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float ig = fsig(acc[0][r]), fg = fsig(acc[1][r]), gg = ftanh(acc[2][r]), og = fsig(acc[3][r]);
@@ -474,23 +545,27 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
                     hs[1][pr ^ 1][4 * rb + r][u] = hn;
                     kp[(0 * 4 + r) * 256] = ig; kp[(1 * 4 + r) * 256] = fg; kp[(2 * 4 + r) * 256] = gg; kp[(3 * 4 + r) * 256] = og;
                     kp[(4 * 4 + r) * 256] = c;
-                    ap[r] = hn * wa0;                       // hid2act, acceleration channel: partial over this wave's 16 units
+                    ap[r] = hn * wa0;                       // hid2act: partials over this wave's 16 units
+                    aq[r] = hn * wa1;
                 }
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ap[r] += __shfl_xor(ap[r], o);
+                    for (int r = 0; r < 4; ++r) { ap[r] += __shfl_xor(ap[r], o); aq[r] += __shfl_xor(aq[r], o); }
                 if (n == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) actp[t][wv][4 * rb + r] = ap[r];
+                    for (int r = 0; r < 4; ++r) { actp[0][t][wv][4 * rb + r] = ap[r]; actp[1][t][wv][4 * rb + r] = aq[r]; }
                 }
                 __syncthreads();
             }
         }
         // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
         if (tid < AG) {
-            for (int t = 0; t < GT; ++t) actp[t][0][tid] = actp[t][0][tid] + actp[t][1][tid] + actp[t][2][tid] + actp[t][3][tid] + bh2a;
-            speed_chain_grad(d, a, agent(tid), &actp[0][0][tid], 4 * AG, &dact[tid][0]);
+            for (int t = 0; t < GT; ++t) {
+                actp[0][t][0][tid] = actp[0][t][0][tid] + actp[0][t][1][tid] + actp[0][t][2][tid] + actp[0][t][3][tid] + bh2a;
+                actp[1][t][0][tid] = actp[1][t][0][tid] + actp[1][t][1][tid] + actp[1][t][2][tid] + actp[1][t][3][tid] + bh2b;
+            }
+            chain_grad(d, a, agent(tid), &actp[0][0][0][tid], &actp[1][0][0][tid], 4 * AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
         }
         __syncthreads();
         // ---------------- backward through time ----------------
@@ -533,7 +608,7 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
                 for (int r = 0; r < 4; ++r) {
                     const float ig = kv1[0][r], fg = kv1[1][r], gg = kv1[2][r], og = kv1[3][r], c = kv1[4][r], cp = kv1[5][r];
                     const float tc = ftanh(c);
-                    const float dh = wa0 * dact[4 * rb + r][t] + rec1[r];
+                    const float dh = wa0 * dact[4 * rb + r][0][t] + wa1 * dact[4 * rb + r][1][t] + rec1[r];
                     const float dc = dh * og * (1.f - tc * tc) + dc1n[r];
                     float* row = &dG[0][4 * rb + r][u];
                     row[0] = dc * gg * ig * (1.f - ig);

@@ -142,7 +142,7 @@ class Engine:
 
     def _guidance(self, g: Mapping, B: int):
         """dict(curr_states [B,4], target_speed [B,52] | None, loss_scale [B] | None, speed_limit (limit, scale) | None,
-        acc_limit (limit, scale) | None, lr | None, perturb_th | None | "sigma", optimizer "adam" | "sgd")
+        acc_limit (limit, scale) | None, target_pos (pos [B,2], time index [B], scale) | None, lr | None, perturb_th | None | "sigma", optimizer "adam" | "sgd")
         -> (CldGuidance, tensors kept alive).  A `scale` is a per-agent tensor [B] (weight / (agents of the scene * 52),
         as DiffuserGuidance averages) or a scalar weight (divided by 52 here).  lr None = sigma_t; perturb_th None = no clip (what
         the reference's perturb() does), "sigma" = clip to sigma_t, a number = clip to it (include/cld.h)."""
@@ -159,6 +159,14 @@ class Engine:
             return float(lim), sc
         sl, sls = term("speed_limit")
         al, als = term("acc_limit")
+        tp = tt = tps = None
+        if g.get("target_pos") is not None:      # (positions [B,2], time index [B], per-agent scale [B] | scalar weight): TargetPosAtTimeLoss
+            pos_, time_, sc = g["target_pos"]
+            tp = self._f32(pos_, (B, 2))
+            tt = torch.as_tensor(time_).to(self.device, torch.int32).contiguous()
+            if tuple(tt.shape) != (B,):
+                raise CldError(f"target_pos time index: expected shape ({B},), got {tuple(tt.shape)}")
+            tps = torch.full((B,), float(sc), device=self.device) if not isinstance(sc, torch.Tensor) and np.isscalar(sc) else self._f32(sc, (B,))
         th = g.get("perturb_th")
         opt = g.get("optimizer", "adam")
         if opt not in _lib.OPTIMIZERS:
@@ -166,8 +174,10 @@ class Engine:
         cg = _lib.CldGuidance(cs.data_ptr(), None if ts is None else ts.data_ptr(), None if ls is None else ls.data_ptr(),
                               float(g["lr"]) if g.get("lr") else 0.0,
                               -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
-                              sl, al, None if sls is None else sls.data_ptr(), None if als is None else als.data_ptr())
-        return cg, (cs, ts, ls, sls, als)
+                              sl, al, None if sls is None else sls.data_ptr(), None if als is None else als.data_ptr(),
+                              None if tp is None else tp.data_ptr(), None if tt is None else tt.data_ptr(),
+                              None if tps is None else tps.data_ptr())
+        return cg, (cs, ts, ls, sls, als, tp, tt, tps)
 
     def guidance_step(self, mean, cond, guidance: Mapping, sigma: float, z=None, want_grad=False):
         """One guidance step on a posterior mean [B,52,4] (upstream PerturbationGuidance.perturb, guidance_loss.py:2221-2282)

@@ -144,7 +144,8 @@ int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const flo
  * at every step t > 0 the posterior mean mu is decoded to a trajectory, the guidance loss
  *     L = sum_agents loss_scale[b] * sum_t |v_t - target_speed[b,t]|         (TargetSpeedLoss, guidance_loss.py:219-254;
  *         loss_scale[b] = weight / (agents guided in b's scene * 52) reproduces DiffuserGuidance.compute_guidance_loss :2143-2175)
- *       [+ SpeedLimitLoss and AccLimitLoss terms, see the struct; any combination, as upstream sums its configured losses]
+ *       [+ SpeedLimitLoss, AccLimitLoss and TargetPosAtTimeLoss terms, see the struct; any combination, as upstream sums its
+ *          configured losses]
  * is differentiated through the roll-out and the decoder down to mu, ONE optimiser step is taken on mu
  * (Adam's first step: delta = -lr * g / (|g| + 1e-8); SGD: delta = -lr * g; scene_edit_config.py:74-90 defaults adam,
  * lr 0.3, grad_steps 1), and x_{t-1} = mu + delta + sigma_t z.  Step t = 0 is not guided (apply_guidance_output = False).
@@ -168,6 +169,12 @@ typedef struct cld_guidance {
     float acc_limit;                   /* m/s^2 */
     const float* speed_limit_scale;    /* [B] or NULL */
     const float* acc_limit_scale;      /* [B] or NULL */
+    /* TargetPosAtTimeLoss (guidance_loss.py:632-670): sum_b target_pos_scale[b] * |(x, y)[target_time[b]] - target_pos[b]|,
+     * differentiated through the whole unicycle roll-out (positions, yaw, the speed-dependent yaw-rate bound);
+     * off when target_pos_scale is NULL */
+    const float* target_pos;           /* [B,2] waypoint in the agent frame */
+    const int32_t* target_time;        /* [B] index 0..51 of the trajectory state that should hit it */
+    const float* target_pos_scale;     /* [B] or NULL */
 } cld_guidance;
 
 /* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */

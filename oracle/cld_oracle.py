@@ -413,7 +413,7 @@ def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, tap
 # f-3  sampling-time guidance (upstream diffuser.py:844-929, guidance_loss.py:219-254,2221-2282)
 # --------------------------------------------------------------------------- #
 def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Optional[Tensor], loss_scale: Optional[Tensor],
-                  lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None):
+                  lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None, target_pos=None):
     """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282, grad_steps = 1) with decoder = `decode` and
     TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target| (+ optional SpeedLimitLoss / AccLimitLoss
     terms, each a (limit, per-agent scale) pair); Adam's first step is
@@ -433,6 +433,10 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
             loss = loss + ((traj[..., 2].abs() - speed_limit[0]).clamp(min=0).sum(dim=1) * speed_limit[1]).sum()
         if acc_limit is not None:          # (limit, scale [B]): AccLimitLoss, guidance_loss.py:1444-1467
             loss = loss + ((traj[..., 4].abs() - acc_limit[0]).clamp(min=0).sum(dim=1) * acc_limit[1]).sum()
+        if target_pos is not None:         # (pos [B,2], time index [B], scale [B]): TargetPosAtTimeLoss, guidance_loss.py:632-670
+            p_, t_, s_ = target_pos
+            hit = traj[torch.arange(traj.shape[0]), t_.long(), :2]
+            loss = loss + ((hit - p_).norm(dim=-1) * s_).sum()
         (g,) = torch.autograd.grad(loss, x)
     delta = -lr * g / (g.abs() + 1e-8) if optimizer == "adam" else -lr * g
     if perturb_th is not None:

@@ -214,9 +214,21 @@ def section_guidance(ref):
     xg, _ = pg.perturb(mean.clone(), {"scene_index": scene_index}, {"optimizer": "sgd", "lr": 5.0, "grad_steps": 1, "perturb_th": None},
                        num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
     out["guided_combo_sgd"] = xg.detach()
+    # waypoint guidance: TargetPosAtTimeLoss on scene 0 (3 agents) + target speed on scene 1
+    wp = synth.uniform(IN_SEED, "guide_waypoint", (3, 2), -5.0, 25.0)
+    wt = np.array([10, 51, 30])
+    cfg_wp = [[{"name": "target_pos_at_time", "weight": 2.0, "params": {"target_pos": wp, "target_time": wt}, "agents": None}],
+              [{"name": "target_speed", "weight": 1.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None}]]
+    pg = gl.PerturbationGuidance(transform=lambda x, data_batch, params, bsize, num_samp: x, transform_params=None)
+    pg.set_guidance(cfg_wp)
+    xg, _ = pg.perturb(mean.clone(), {"scene_index": scene_index}, {"optimizer": "sgd", "lr": 0.05, "grad_steps": 1, "perturb_th": None},
+                       num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
+    out["guided_waypoint_sgd"] = xg.detach()
     save("guidance", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "mean": "normal(in_seed,'guide_mean')",
                       "target_speed": "uniform(in_seed,'guide_target_speed',0,12)", "scenes": [3, 5], "weights": [1.0, 2.0],
                       "adam": {"lr": 0.3, "perturb_th": 0.2}, "sgd": {"lr": 5.0, "perturb_th": 0.5},
+                      "waypoint_sgd": {"lr": 0.05, "weight": 2.0, "target_time": [10, 51, 30], "target_pos": "uniform(in_seed,'guide_waypoint',(3,2),-5,25)",
+                                       "scene1_target_speed_weight": 1.0},
                       "combo_sgd": {"lr": 5.0, "scene0": {"target_speed": 1.0, "speed_limit": [6.0, 0.5], "acc_limit": [0.1, 4.0]},
                                     "scene1": {"speed_limit": [6.0, 3.0]}},
                       "decoder": "oracle.decode (pinned by decode.npz)"}, **out)

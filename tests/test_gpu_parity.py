@@ -457,3 +457,74 @@ def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
     # a speed limit alone (no target-speed term) is accepted too
     only = eng_jitter.guidance_step(mean, cond, {"curr_states": cs, "speed_limit": (6.0, 1.0), "lr": 1.0, "optimizer": "sgd"}, sigma=0.5)
     assert bool(torch.isfinite(only).all())
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_guidance_waypoint_golden(golden, eng_jitter, kernel):
+    """Waypoint guidance (TargetPosAtTimeLoss): the gradient runs through positions, yaw and the speed-dependent yaw-rate
+    bound of the unicycle roll-out, then through both decoder output channels.  Against the reference's perturb() (golden
+    'guidance', waypoint_sgd) and, for the raw gradient, against the oracle's autograd."""
+    import os
+    from oracle import cld_oracle as O
+    meta, g = golden("guidance")
+    cond, cs, mean, tgt, _ = _guidance_inputs(meta)
+    c = meta["waypoint_sgd"]
+    n0, n1 = meta["scenes"]
+    wp = torch.zeros(meta["B"], 2); wp[:n0] = torch.from_numpy(synth.uniform(meta["in_seed"], "guide_waypoint", (n0, 2), -5.0, 25.0))
+    wt = torch.tensor(c["target_time"] + [0] * n1)
+    tps = torch.tensor([c["weight"] / n0] * n0 + [0.0] * n1)
+    ts = torch.tensor([0.0] * n0 + [c["scene1_target_speed_weight"] / (n1 * 52)] * n1)
+    gd = {"curr_states": cs, "target_speed": tgt, "loss_scale": ts, "target_pos": (wp, wt, tps), "lr": c["lr"], "perturb_th": None,
+          "optimizer": "sgd"}
+    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    try:
+        mg, grad = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["CLD_GUIDE_KERNEL"]
+    _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, tgt, ts, c["lr"], None, "sgd", target_pos=(wp, wt, tps))
+    assert (grad.cpu() - gref).abs().max().item() <= 5e-5 * gref.abs().max().item()
+    step = np.abs(g["guided_waypoint_sgd"] - mean.numpy()).max()
+    assert np.abs(mg.cpu().numpy() - g["guided_waypoint_sgd"]).max() <= max(5e-5 * step, 2.5e-7)
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_guidance_waypoint_yaw_bound_path(kernel):
+    """The yaw-rate clip of the roll-out (bound = max(min(0.5|v|, 2pi/|v|), 0.1)) routes the waypoint gradient into the speed
+    when it is active.  The reference statistics never reach it with random weights, so this case widens the yaw-rate scale
+    (std[5] = 4) and starts agents slowly; gradient against the oracle's autograd with the same statistics."""
+    import os
+    from cld_amd.engine import Engine
+    from oracle import cld_oracle as O
+    mean6, std6 = list(O.NORM_MEAN), list(O.NORM_STD)
+    std6[5] = 4.0
+    e = Engine(n_timesteps=10, device="cuda:0", norm_info=(mean6, std6))
+    e.load_state_dict(synth.make_unet_weights(0)); e.load_state_dict(synth.make_decoder_weights(0)); e.finalize()
+    B = 24
+    inp = synth.make_inputs(B, 31)
+    cond = torch.from_numpy(inp["cond_feat"])
+    cs = torch.from_numpy(inp["curr_states"]).clone()
+    cs[:, 2] = torch.from_numpy(synth.uniform(31, "slow", (B,), 0.05, 4.0))
+    mean = torch.from_numpy(synth.normal(31, "guide_mean", (B, 52, 4)))
+    wp = torch.from_numpy(synth.uniform(31, "wp", (B, 2), -3.0, 10.0))
+    wt = torch.from_numpy(synth.uniform(31, "wt", (B,), 5.0, 51.9)).long()
+    tps = torch.full((B,), 1.0 / B)
+    gd = {"curr_states": cs, "target_pos": (wp, wt, tps), "lr": 1.0, "perturb_th": None, "optimizer": "sgd"}
+    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    old = O.NORM_STD
+    try:
+        _, grad = e.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+        torch.cuda.synchronize()
+        O.NORM_STD = tuple(std6)
+        wdec = O.to_torch(synth.make_decoder_weights(0))
+        _, gref = O.guidance_step(wdec, mean, cond, cs, None, None, 1.0, None, "sgd", target_pos=(wp, wt, tps))
+        with torch.no_grad():      # the case must actually clip: yaw rates beyond the bound on a fair share of steps
+            traj = O.decode(wdec, mean, cond, cs, True)
+            v_prev = torch.cat([cs[:, 2:3].clamp(-10, 30), traj[:, :-1, 2]], dim=1).abs()
+            yb = torch.minimum(0.5 * v_prev, 2 * np.pi / v_prev.clamp(min=0.1)).clamp(min=0.1)
+            clipped = (traj[..., 5].abs() > yb).float().mean().item()
+    finally:
+        O.NORM_STD = old
+        del os.environ["CLD_GUIDE_KERNEL"]
+    assert clipped > 0.05, clipped
+    assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()

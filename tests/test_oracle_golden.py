@@ -236,3 +236,19 @@ def test_guidance_combined_losses_vs_reference_perturb(golden):
                             acc_limit=(c["scene0"]["acc_limit"][0], al))
     assert np.abs(xg.numpy() - g["guided_combo_sgd"]).max() <= 2e-6
     assert np.abs(g["guided_combo_sgd"] - g["guided_sgd"]).max() > 1e-3          # the extra terms do change the step
+
+
+def test_guidance_waypoint_vs_reference_perturb(golden):
+    """TargetPosAtTimeLoss (guidance_loss.py:632-670) on one scene + target speed on the other through the reference's perturb():
+    pins the loss and, through autograd, the whole unicycle roll-out of the oracle's decode."""
+    meta, g = golden("guidance")
+    cond, cs, mean, tgt, _ = _guidance_inputs(meta)
+    c = meta["waypoint_sgd"]
+    n0, n1 = meta["scenes"]
+    wp = torch.zeros(meta["B"], 2); wp[:n0] = torch.from_numpy(synth.uniform(meta["in_seed"], "guide_waypoint", (n0, 2), -5.0, 25.0))
+    wt = torch.tensor(c["target_time"] + [0] * n1)
+    tps = torch.tensor([c["weight"] / n0] * n0 + [0.0] * n1)
+    ts = torch.tensor([0.0] * n0 + [c["scene1_target_speed_weight"] / (n1 * 52)] * n1)
+    xg, _ = O.guidance_step(O.to_torch(synth.make_decoder_weights(meta["w_seed"])), mean, cond, cs, tgt, ts, c["lr"], None, "sgd",
+                            target_pos=(wp, wt, tps))
+    assert np.abs(xg.numpy() - g["guided_waypoint_sgd"]).max() <= 2e-6
