@@ -33,13 +33,15 @@ constexpr int GT = 52;
 //   L = s_ts * sum_t |v_{t+1} - target_t|                       TargetSpeedLoss      :219-254
 //     + s_sl * sum_t relu(|v_{t+1}| - speed_limit)               SpeedLimitLoss       :1509-1538
 //     + s_al * sum_t relu(|acc_t| - acc_limit)                   AccLimitLoss         :1444-1467 (unclipped descaled action)
-//     + s_tp * |(x, y)_{T*+1} - target_pos|                      TargetPosAtTimeLoss  :632-670
+//     + s_tp * |(x, y)_{T*+1} - target_pos|                      TargetPosAtTimeLoss  :632-670   (target_time = T* >= 0)
+//       or s_tp * mean_{t >= m} softmin_t(dist) dist_t^2           TargetPosLoss        :672-716   (target_time = -(m + 1) < 0)
 // act0 / act1 [t * st] in; dact0 / dact1 [t] = dL / d act out.  min / max / clamp pass gradients like torch (clamp: on
 // [lo, hi]; an active bound of the yaw-rate clip routes the gradient into yb and from there into v_k).
-// sc: 4 x 54 floats of per-agent scratch (v_k, th_k, dL/dv_k, dL/dth_k).
+// sc: 6 x 54 floats of per-agent scratch (v_k, th_k, dL/dv_k, clip mask of v_k, dL/dx_k, dL/dy_k).
 __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& a, int b, const float* act0, const float* act1, int st,
                                            float* dact0, float* dact1, float* sc) {
     float* vk = sc; float* th = sc + 54; float* gv = sc + 108; float* gth = sc + 162;   // gth: clip mask of v_k (1 = inside the bounds)
+    float* gxk = sc + 216; float* gyk = sc + 270;                                        // direct dL/dx_{k+1}, dL/dy_{k+1} (positions first)
     const float* cs = a.curr_states + (size_t)b * 4;
     const float* tgt = a.target_speed ? a.target_speed + (size_t)b * GT : nullptr;
     const float s_ts = tgt ? (a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT)) : 0.f;
@@ -53,8 +55,7 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
     th[0] = yaw;
     gv[0] = 0.f;
     int tstar = 0;
-    float px = 0.f, py = 0.f;
-    if (pos) { tstar = a.target_time[b]; tstar = tstar < 0 ? 0 : (tstar > GT - 1 ? GT - 1 : tstar); }
+    if (pos) { tstar = a.target_time[b]; tstar = tstar > GT - 1 ? GT - 1 : tstar; }
     for (int t = 0; t < GT; ++t) {
         const float acc = act0[t * st] * d.std[4] + d.mean[4];
         v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
@@ -79,24 +80,51 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
             y += vbar * sinf(yaw) * d.dt;
             yaw += wc * d.dt;
             th[t + 1] = yaw;
-            if (t == tstar) { px = x; py = y; }
+            gxk[t] = x; gyk[t] = y;             // positions for now
+        }
+    }
+    if (pos) {      // positions -> direct position gradients
+        const float wx = a.target_pos[2 * b], wy = a.target_pos[2 * b + 1];
+        if (tstar >= 0) {                       // hit the waypoint AT step tstar: d|e|/de (torch.norm: 0 at 0)
+            const float ex = gxk[tstar] - wx, ey = gyk[tstar] - wy;
+            const float nrm = sqrtf(ex * ex + ey * ey);
+            for (int t = 0; t < GT; ++t) { gxk[t] = 0.f; gyk[t] = 0.f; }
+            if (nrm > 0.f) { gxk[tstar] = s_tp * ex / nrm; gyk[tstar] = s_tp * ey / nrm; }
+        } else {                                // hit it at SOME step >= m: L = mean_t w_t dist_t^2, w = softmin(dist)
+            int m = -tstar - 1;
+            m = m > GT - 1 ? GT - 1 : m;
+            float dmin = 3.4e38f;
+            for (int t = m; t < GT; ++t) {
+                const float ex = gxk[t] - wx, ey = gyk[t] - wy;
+                dmin = fminf(dmin, sqrtf(ex * ex + ey * ey));
+            }
+            float z = 0.f, S = 0.f;
+            for (int t = m; t < GT; ++t) {
+                const float ex = gxk[t] - wx, ey = gyk[t] - wy;
+                const float dd = sqrtf(ex * ex + ey * ey), e = expf(-(dd - dmin));
+                z += e; S += e * dd * dd;
+            }
+            S /= z;
+            const float inv = s_tp / (float)(GT - m);
+            for (int t = 0; t < GT; ++t) {
+                if (t < m) { gxk[t] = 0.f; gyk[t] = 0.f; continue; }
+                const float ex = gxk[t] - wx, ey = gyk[t] - wy;
+                const float dd = sqrtf(ex * ex + ey * ey), wgt = expf(-(dd - dmin)) / z;
+                // d/dp_t [ sum_s w_s dist_s^2 ] = w_t (2 e_t + (S - dist_t^2) e_t / dist_t)
+                const float k = inv * wgt * (2.f + (dd > 0.f ? (S - dd * dd) / dd : 0.f));
+                gxk[t] = k * ex; gyk[t] = k * ey;
+            }
         }
     }
     // ---- backward ----
     float gx = 0.f, gy = 0.f;                   // dL/dx_{k+1}, dL/dy_{k+1} summed over k >= current step (suffix sums)
-    float tx = 0.f, ty = 0.f;
-    if (pos) {
-        const float ex = px - a.target_pos[2 * b], ey = py - a.target_pos[2 * b + 1];
-        const float nrm = sqrtf(ex * ex + ey * ey);
-        if (nrm > 0.f) { tx = s_tp * ex / nrm; ty = s_tp * ey / nrm; }          // d|e|/de (torch.norm: 0 at 0)
-    }
     float g_th_suffix = 0.f;                    // sum_{m > k} dL/dth_m
     float run_v = 0.f;                          // sum_{k > j} dL/dv_raw_k
     float d_vbar_next = 0.f;                    // dL/dvbar_{k+1}
     for (int k = GT - 1; k >= 0; --k) {
         float d_w = 0.f, d_vk_from_yb = 0.f, d_vbar = 0.f;
         if (pos) {
-            if (k == tstar) { gx += tx; gy += ty; }
+            gx += gxk[k]; gy += gyk[k];
             float sn, cn;
             sincosf(th[k], &sn, &cn);
             const float vbar = 0.5f * (vk[k] + vk[k + 1]);
@@ -165,7 +193,7 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
     __shared__ __attribute__((aligned(16))) float condm[NA][256];
     __shared__ float act[NA][2][GT];         // scaled (acceleration, yaw-rate) output of the decoder
     __shared__ float dact[NA][2][GT];        // dL / d(scaled output)
-    __shared__ float chs[NA][216];           // roll-out scratch of chain_grad
+    __shared__ float chs[NA][324];           // roll-out scratch of chain_grad
     __shared__ __attribute__((aligned(16))) float dgl[NA][256];           // gate gradients of the layer being processed
     __shared__ float part[3][NA][4][64];     // partial transposed products
     __shared__ float rec1[NA][64], rec0[NA][64], dh0l1[NA][64], dc1n[NA][64], dc0n[NA][64];
@@ -437,7 +465,7 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
     __shared__ __attribute__((aligned(16))) float condm[AG][256];
     __shared__ float actp[2][GT][4][AG];     // per-wave partials of the (acceleration, yaw-rate) output
     __shared__ float dact[AG][2][GT];
-    __shared__ float chs[AG][216];           // roll-out scratch of chain_grad
+    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
     __shared__ float dzp[2][4][AG][4];       // per-wave partials of dL/dz_t, by step parity
     __shared__ float dz[AG][208];
     const int tid = threadIdx.x, lane = tid & 63;

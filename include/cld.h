@@ -173,7 +173,9 @@ typedef struct cld_guidance {
      * differentiated through the whole unicycle roll-out (positions, yaw, the speed-dependent yaw-rate bound);
      * off when target_pos_scale is NULL */
     const float* target_pos;           /* [B,2] waypoint in the agent frame */
-    const int32_t* target_time;        /* [B] index 0..51 of the trajectory state that should hit it */
+    const int32_t* target_time;        /* [B] >= 0: index 0..51 of the trajectory state that should hit it;
+                                        *     < 0: TargetPosLoss (:672-716) instead -- hit it at SOME state >= m = -(value + 1):
+                                        *          target_pos_scale[b] * mean_{t >= m} softmin_t(dist) * dist_t^2 */
     const float* target_pos_scale;     /* [B] or NULL */
 } cld_guidance;
 

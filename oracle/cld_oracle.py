@@ -435,8 +435,14 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
             loss = loss + ((traj[..., 4].abs() - acc_limit[0]).clamp(min=0).sum(dim=1) * acc_limit[1]).sum()
         if target_pos is not None:         # (pos [B,2], time index [B], scale [B]): TargetPosAtTimeLoss, guidance_loss.py:632-670
             p_, t_, s_ = target_pos
-            hit = traj[torch.arange(traj.shape[0]), t_.long(), :2]
-            loss = loss + ((hit - p_).norm(dim=-1) * s_).sum()
+            for bb in range(traj.shape[0]):        # t >= 0: hit at that step; t < 0: TargetPosLoss (:672-716), any step >= -(t + 1)
+                tb = int(t_[bb])
+                if tb >= 0:
+                    loss = loss + (traj[bb, tb, :2] - p_[bb]).norm() * s_[bb]
+                else:
+                    e = traj[bb, -tb - 1:, :2] - p_[bb]
+                    dist = e.norm(dim=-1)
+                    loss = loss + (F.softmin(dist, dim=-1) * (e ** 2).sum(dim=-1)).mean() * s_[bb]
         (g,) = torch.autograd.grad(loss, x)
     delta = -lr * g / (g.abs() + 1e-8) if optimizer == "adam" else -lr * g
     if perturb_th is not None:

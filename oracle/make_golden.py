@@ -224,11 +224,19 @@ def section_guidance(ref):
     xg, _ = pg.perturb(mean.clone(), {"scene_index": scene_index}, {"optimizer": "sgd", "lr": 0.05, "grad_steps": 1, "perturb_th": None},
                        num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
     out["guided_waypoint_sgd"] = xg.detach()
+    # TargetPosLoss (softmin over the second half of the horizon) on scene 0
+    cfg_tp = [[{"name": "target_pos", "weight": 0.5, "params": {"target_pos": wp, "min_target_time": 0.5}, "agents": None}], []]
+    pg = gl.PerturbationGuidance(transform=lambda x, data_batch, params, bsize, num_samp: x, transform_params=None)
+    pg.set_guidance(cfg_tp)
+    xg, _ = pg.perturb(mean.clone(), {"scene_index": scene_index}, {"optimizer": "sgd", "lr": 0.05, "grad_steps": 1, "perturb_th": None},
+                       num_samp=1, decoder=lambda x: O.decode(wdec, x, cond, cs, True))
+    out["guided_targetpos_sgd"] = xg.detach()
     save("guidance", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "mean": "normal(in_seed,'guide_mean')",
                       "target_speed": "uniform(in_seed,'guide_target_speed',0,12)", "scenes": [3, 5], "weights": [1.0, 2.0],
                       "adam": {"lr": 0.3, "perturb_th": 0.2}, "sgd": {"lr": 5.0, "perturb_th": 0.5},
                       "waypoint_sgd": {"lr": 0.05, "weight": 2.0, "target_time": [10, 51, 30], "target_pos": "uniform(in_seed,'guide_waypoint',(3,2),-5,25)",
                                        "scene1_target_speed_weight": 1.0},
+                      "targetpos_sgd": {"lr": 0.05, "weight": 0.5, "min_target_time": 0.5},
                       "combo_sgd": {"lr": 5.0, "scene0": {"target_speed": 1.0, "speed_limit": [6.0, 0.5], "acc_limit": [0.1, 4.0]},
                                     "scene1": {"speed_limit": [6.0, 3.0]}},
                       "decoder": "oracle.decode (pinned by decode.npz)"}, **out)

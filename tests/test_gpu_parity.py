@@ -528,3 +528,29 @@ def test_guidance_waypoint_yaw_bound_path(kernel):
         del os.environ["CLD_GUIDE_KERNEL"]
     assert clipped > 0.05, clipped
     assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+def test_guidance_targetpos_softmin_golden(golden, eng_jitter, kernel):
+    """TargetPosLoss (softmin over the steps >= m, encoded as target_time = -(m + 1)) against the reference's perturb()."""
+    import os
+    from oracle import cld_oracle as O
+    meta, g = golden("guidance")
+    cond, cs, mean, _, _ = _guidance_inputs(meta)
+    c = meta["targetpos_sgd"]
+    n0, n1 = meta["scenes"]
+    wp = torch.zeros(meta["B"], 2); wp[:n0] = torch.from_numpy(synth.uniform(meta["in_seed"], "guide_waypoint", (n0, 2), -5.0, 25.0))
+    m = int(c["min_target_time"] * 52)
+    wt = torch.tensor([-(m + 1)] * n0 + [0] * n1)
+    tps = torch.tensor([c["weight"] / n0] * n0 + [0.0] * n1)
+    gd = {"curr_states": cs, "target_pos": (wp, wt, tps), "lr": c["lr"], "perturb_th": None, "optimizer": "sgd"}
+    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    try:
+        mg, grad = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["CLD_GUIDE_KERNEL"]
+    _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, None, None, c["lr"], None, "sgd", target_pos=(wp, wt, tps))
+    assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
+    step = np.abs(g["guided_targetpos_sgd"] - mean.numpy()).max()
+    assert np.abs(mg.cpu().numpy() - g["guided_targetpos_sgd"]).max() <= max(1e-4 * step, 2.5e-7)

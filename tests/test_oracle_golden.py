@@ -252,3 +252,19 @@ def test_guidance_waypoint_vs_reference_perturb(golden):
     xg, _ = O.guidance_step(O.to_torch(synth.make_decoder_weights(meta["w_seed"])), mean, cond, cs, tgt, ts, c["lr"], None, "sgd",
                             target_pos=(wp, wt, tps))
     assert np.abs(xg.numpy() - g["guided_waypoint_sgd"]).max() <= 2e-6
+
+
+def test_guidance_targetpos_softmin_vs_reference_perturb(golden):
+    """TargetPosLoss (guidance_loss.py:672-716: softmin-weighted squared distance over the second half of the horizon)
+    through the reference's perturb()."""
+    meta, g = golden("guidance")
+    cond, cs, mean, _, _ = _guidance_inputs(meta)
+    c = meta["targetpos_sgd"]
+    n0, n1 = meta["scenes"]
+    wp = torch.zeros(meta["B"], 2); wp[:n0] = torch.from_numpy(synth.uniform(meta["in_seed"], "guide_waypoint", (n0, 2), -5.0, 25.0))
+    m = int(c["min_target_time"] * 52)
+    wt = torch.tensor([-(m + 1)] * n0 + [0] * n1)
+    tps = torch.tensor([c["weight"] / n0] * n0 + [0.0] * n1)
+    xg, _ = O.guidance_step(O.to_torch(synth.make_decoder_weights(meta["w_seed"])), mean, cond, cs, None, None, c["lr"], None, "sgd",
+                            target_pos=(wp, wt, tps))
+    assert np.abs(xg.numpy() - g["guided_targetpos_sgd"]).max() <= 2e-6
