@@ -130,9 +130,14 @@ class DmModel:
         if guidance is not None:
             guidance = dict(guidance)
             guidance.setdefault("curr_states", aux_info["curr_states"])
+            def rep(v):                       # per-agent tensors follow the num_samp repeat of the batch (dm_model.py:116)
+                return repeat_by_expand_at(v, num_samp, 0) if isinstance(v, torch.Tensor) and v.dim() >= 1 else v
             for k in ("target_speed", "loss_scale"):
                 if guidance.get(k) is not None:
-                    guidance[k] = repeat_by_expand_at(torch.as_tensor(guidance[k]), num_samp, 0)
+                    guidance[k] = rep(torch.as_tensor(guidance[k]))
+            for k in ("speed_limit", "acc_limit", "target_pos"):
+                if guidance.get(k) is not None:
+                    guidance[k] = tuple(rep(v) for v in guidance[k])
         x0, x1, logp = self.engine.sample(x_T, aux_info["cond_feat"], noise=z, seed=seed,
                                           non_cond=aux_info.get("non_cond_feat") if class_free_guide_w else None,
                                           guidance_w=class_free_guide_w, guidance=guidance)

@@ -52,9 +52,18 @@ class CldPolicy:
         self.context_encoder = context_encoder
         self.disable_control_on_stationary = disable_control_on_stationary   # config.yaml:99
         self.moving_speed_th = moving_speed_th                               # config.yaml:101
+        self._guidance = None
 
     def eval(self):
         return self
+
+    def set_guidance(self, guidance_config_list, scene_index, **opt):
+        """Upstream `set_guidance` (algos.py; guidance_loss.py:2106-2175): keep a guidance configuration for the following
+        `get_action` calls.  `opt`: lr / optimizer / perturb_th of the optimiser step (scene_edit_config.py:74-90)."""
+        self._guidance = dict(guidance_from_config(guidance_config_list, scene_index), **opt)
+
+    def clear_guidance(self):
+        self._guidance = None
 
     @torch.no_grad()
     def get_action(self, obs_dict: Mapping, num_action_samples: int = 1, class_free_guide_w: float = 0.0,
@@ -66,7 +75,8 @@ class CldPolicy:
         cond, cs = aux["cond_feat"], aux["curr_states"]
         B, N = cond.shape[0], int(num_action_samples)
         out = self.dm({"history_positions": cond}, {k: aux[k] for k in ("cond_feat", "curr_states", "non_cond_feat") if k in aux},
-                      {"num_samp": N}, noise=noise, class_free_guide_w=class_free_guide_w, guidance=guidance)
+                      {"num_samp": N}, noise=noise, class_free_guide_w=class_free_guide_w,
+                      guidance=guidance if guidance is not None else self._guidance)
         a = out["aux_info"]
         traj = self.vae.engine.decode(out["pred_traj"], a["cond_feat"], a["curr_states"], descaled_output=True)
         traj = traj.reshape(B, N, 52, 6)
@@ -110,3 +120,71 @@ def closed_loop_rollout(policy: CldPolicy, cond_fn: Callable, centroid, yaw, cur
                 world, cs = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), n_step_action - 1)
         poses.append(world)
     return torch.stack(poses)
+
+
+def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52) -> dict:
+    """Upstream's guidance configuration -> the `guidance=` dict of `DmModel.forward` / `Engine.sample`.
+
+    `guidance_config_list` is what `DiffuserTrafficModel.set_guidance` takes (`src/tbsim/algos/algos.py`, built by
+    `DiffuserGuidance`, `src/tbsim/utils/guidance_loss.py:2106-2175`): one list per scene of
+    `{'name', 'weight', 'params', 'agents'}` dicts; `scene_index [B]` maps agents to scenes (consecutive runs).  Each loss
+    is averaged over the agents it applies to within its scene and multiplied by its weight; that is folded into the
+    per-agent scales of the kernel: weight / (agents * horizon) for the per-step losses, weight / agents for the waypoint
+    losses.  Supported names: target_speed, speed_limit, acc_limit, target_pos_at_time, target_pos (the others couple
+    agents or sample the raster and are not built).  One speed / acceleration limit value per call."""
+    scene_index = torch.as_tensor(scene_index).reshape(-1).cpu()
+    B = scene_index.numel()
+    _, local = torch.unique_consecutive(scene_index, return_inverse=True)
+    if len(guidance_config_list) != int(local.max()) + 1:
+        raise ValueError("guidance config list must hold one entry per scene")
+    out: dict = {}
+    ts_scale = torch.zeros(B); ts = torch.zeros(B, horizon); has_ts = False
+    sl_scale = torch.zeros(B); al_scale = torch.zeros(B); sl = al = None
+    tp = torch.zeros(B, 2); tt = torch.zeros(B, dtype=torch.int32); tp_scale = torch.zeros(B); has_tp = False
+    for si, cfgs in enumerate(guidance_config_list):
+        members = torch.nonzero(local == si).reshape(-1)
+        for cfg in cfgs:
+            name, wgt, prm, agents = cfg["name"], float(cfg["weight"]), cfg["params"], cfg.get("agents")
+            idx = members if agents is None else members[torch.as_tensor(agents, dtype=torch.long)]
+            n = max(1, idx.numel())
+            if name == "target_speed":       # params['target_speed'] is indexed by the whole batch (guidance_loss.py:231-241)
+                if bool((ts_scale[idx] != 0).any()):
+                    raise ValueError("two target_speed losses on one agent")
+                full = torch.as_tensor(prm["target_speed"], dtype=torch.float32)
+                ts[idx] = full[idx, :horizon]
+                ts_scale[idx] = wgt / (n * horizon)
+                has_ts = True
+            elif name in ("speed_limit", "acc_limit"):
+                val = float(prm[name])
+                if name == "speed_limit":
+                    if sl is not None and sl != val:
+                        raise ValueError("one speed_limit value per call")
+                    sl = val; sl_scale[idx] += wgt / (n * horizon)
+                else:
+                    if al is not None and al != val:
+                        raise ValueError("one acc_limit value per call")
+                    al = val; al_scale[idx] += wgt / (n * horizon)
+            elif name in ("target_pos_at_time", "target_pos"):
+                if bool((tp_scale[idx] != 0).any()):
+                    raise ValueError("two waypoint losses on one agent")
+                tp[idx] = torch.as_tensor(prm["target_pos"], dtype=torch.float32).reshape(-1, 2)
+                if name == "target_pos_at_time":
+                    tt[idx] = torch.as_tensor(prm["target_time"], dtype=torch.int32).reshape(-1)
+                else:                        # any step >= int(min_target_time * horizon): encoded as -(m + 1)
+                    tt[idx] = -(int(float(prm.get("min_target_time", 0.0)) * horizon) + 1)
+                tp_scale[idx] = wgt / n
+                has_tp = True
+            else:
+                raise NotImplementedError(f"guidance loss '{name}' is not built (target_speed, speed_limit, acc_limit, "
+                                          f"target_pos_at_time, target_pos are)")
+    if has_ts:
+        out["target_speed"], out["loss_scale"] = ts, ts_scale
+    if sl is not None:
+        out["speed_limit"] = (sl, sl_scale)
+    if al is not None:
+        out["acc_limit"] = (al, al_scale)
+    if has_tp:
+        out["target_pos"] = (tp, tt, tp_scale)
+    if not out:
+        raise ValueError("no guidance loss configured")
+    return out

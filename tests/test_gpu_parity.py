@@ -554,3 +554,34 @@ def test_guidance_targetpos_softmin_golden(golden, eng_jitter, kernel):
     assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
     step = np.abs(g["guided_targetpos_sgd"] - mean.numpy()).max()
     assert np.abs(mg.cpu().numpy() - g["guided_targetpos_sgd"]).max() <= max(1e-4 * step, 2.5e-7)
+
+
+def test_policy_guidance_from_upstream_config(eng10):
+    """CldPolicy.set_guidance with upstream-style per-scene guidance lists, two samples per agent: the guided action equals the
+    engine's guided chain on the repeated batch (bit for bit) and differs from the unguided one."""
+    from cld_amd.dm_model import DmModel
+    from cld_amd.policy import CldPolicy
+    from cld_amd.vae_model import VaeModel
+    dm, vae = DmModel(None, None, n_timesteps=10, engine=eng10), VaeModel(engine=eng10)
+    pol = CldPolicy(dm, vae)
+    B, N = 4, 2
+    inp = synth.make_inputs(B, 9)
+    cond, cs = torch.from_numpy(inp["cond_feat"]).cuda(), torch.from_numpy(inp["curr_states"]).cuda()
+    tgt = synth.uniform(9, "tgt", (B, 52), 0.0, 12.0)
+    cfg = [[{"name": "target_speed", "weight": 1.0, "params": {"target_speed": tgt}, "agents": None}],
+           [{"name": "target_pos_at_time", "weight": 1.0, "params": {"target_pos": [[20.0, 1.0], [15.0, -2.0]], "target_time": [40, 51]}, "agents": None}]]
+    pol.set_guidance(cfg, torch.tensor([0, 0, 1, 1]), lr=0.3, optimizer="adam")
+    nz = synth.make_noise(B * N, 10, 3)
+    noise = {"x_T": torch.from_numpy(nz["x_T"]), "noise": torch.from_numpy(nz["noise"])}
+    act, info = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise)
+    assert info["trajectories"].shape == (B, N, 52, 6)
+    rep = lambda t: t.repeat_interleave(N, dim=0)
+    g = pol._guidance
+    gd = {"curr_states": rep(cs), "target_speed": rep(g["target_speed"]), "loss_scale": rep(g["loss_scale"]),
+          "target_pos": tuple(rep(v) for v in g["target_pos"]), "lr": 0.3, "optimizer": "adam"}
+    x0, _, _ = eng10.sample(noise["x_T"], rep(cond), noise=noise["noise"], guidance=gd)
+    traj = eng10.decode(x0, rep(cond), rep(cs), descaled_output=True).reshape(B, N, 52, 6)
+    assert torch.equal(info["trajectories"], traj)
+    pol.clear_guidance()
+    act0, _ = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise)
+    assert not torch.equal(act0.positions, act.positions)

@@ -174,3 +174,32 @@ def test_timers_keep_the_reference_surface():
     assert s.startswith("network: ") and ", obs: " in s
     assert t._timers["network"].calls == 3 and t._timers["network"].average_time >= 0.002
     assert t.gpu_ms("network") == 0.0 and t.gpu_ms("missing") == 0.0
+
+
+def test_guidance_config_adapter_matches_the_golden_configurations():
+    """policy.guidance_from_config folds upstream's per-scene guidance lists (name / weight / params / agents) into the per-agent
+    scales of the kernel exactly as the golden fixtures were recorded from the reference's DiffuserGuidance (make_golden)."""
+    from cld_amd.policy import guidance_from_config
+    B, T = 8, 52
+    tgt = np.random.RandomState(0).rand(B, T).astype(np.float32)
+    scene_index = torch.tensor([4, 4, 4, 9, 9, 9, 9, 9])
+    wp = np.arange(6, dtype=np.float32).reshape(3, 2)
+    cfg = [[{"name": "target_speed", "weight": 1.0, "params": {"target_speed": tgt}, "agents": None},
+            {"name": "speed_limit", "weight": 0.5, "params": {"speed_limit": 6.0}, "agents": None},
+            {"name": "acc_limit", "weight": 4.0, "params": {"acc_limit": 0.1}, "agents": None},
+            {"name": "target_pos_at_time", "weight": 2.0, "params": {"target_pos": wp, "target_time": [10, 51, 30]}, "agents": None}],
+           [{"name": "speed_limit", "weight": 3.0, "params": {"speed_limit": 6.0}, "agents": None},
+            {"name": "target_pos", "weight": 0.5, "params": {"target_pos": wp[:2], "min_target_time": 0.5}, "agents": [1, 3]}]]
+    g = guidance_from_config(cfg, scene_index)
+    assert torch.allclose(g["loss_scale"], torch.tensor([1.0 / (3 * 52)] * 3 + [0.0] * 5))
+    assert torch.equal(g["target_speed"][:3], torch.from_numpy(tgt[:3])) and float(g["target_speed"][3:].abs().max()) == 0.0
+    assert g["speed_limit"][0] == 6.0 and torch.allclose(g["speed_limit"][1], torch.tensor([0.5 / (3 * 52)] * 3 + [3.0 / (5 * 52)] * 5))
+    assert g["acc_limit"][0] == 0.1 and torch.allclose(g["acc_limit"][1], torch.tensor([4.0 / (3 * 52)] * 3 + [0.0] * 5))
+    pos, tt, sc = g["target_pos"]
+    assert tt.tolist() == [10, 51, 30, 0, -27, 0, -27, 0]                    # scene 1: agents 1 and 3 of the scene, m = 26
+    assert torch.allclose(sc, torch.tensor([2.0 / 3] * 3 + [0.0, 0.25, 0.0, 0.25, 0.0]))
+    assert torch.equal(pos[4], torch.tensor([0.0, 1.0])) and torch.equal(pos[6], torch.tensor([2.0, 3.0]))
+    with pytest.raises(NotImplementedError):
+        guidance_from_config([[{"name": "agent_collision", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
+    with pytest.raises(ValueError):
+        guidance_from_config([[]], scene_index)
