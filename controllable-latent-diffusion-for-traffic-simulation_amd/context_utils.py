@@ -29,11 +29,16 @@ class ContextEncoder:
     def __init__(self, engine: Engine):
         self.engine = engine
 
-    def forward(self, data_batch: dict) -> dict:
+    def forward(self, data_batch: dict, include_class_free_cond: bool = False, cond_fill_value: float = -1.0) -> dict:
+        """`include_class_free_cond` adds aux_info['non_cond_feat'] as upstream builds it for classifier-free guidance
+        (src/tbsim/models/diffuser.py:390-411,459-471): same state features, map features of a raster filled with -1."""
         curr_states = get_current_states(data_batch).to(self.engine.device)
         image = data_batch["image"]
         cond_feat = self.engine.context_encode(image, curr_states)
-        return {"cond_feat": cond_feat, "curr_states": curr_states, "image": image}
+        aux = {"cond_feat": cond_feat, "curr_states": curr_states, "image": image}
+        if include_class_free_cond:
+            aux["non_cond_feat"] = self.engine.non_cond_feat(curr_states, cond_fill_value)
+        return aux
 
     __call__ = forward
 

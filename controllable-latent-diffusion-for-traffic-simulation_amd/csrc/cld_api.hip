@@ -1130,6 +1130,18 @@ int cld_context_encode(cld_handle h, const float* image, const float* curr_state
     return CLD_OK;
 }
 
+int cld_context_combine(cld_handle h, const float* map_feat, int32_t broadcast, const float* curr_states, float* cond_feat,
+                        int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!h->finalized || !h->has_context) return fail(h, CLD_ERR_STATE, "cld_context_combine: context_encoder weights not loaded");
+    if (!map_feat || !curr_states || !cond_feat || B < 1) return fail(h, CLD_ERR_ARG, "cld_context_combine: bad argument");
+    ContextHeadArgs a = h->ctx_head;
+    a.feat = nullptr; a.map_feat_in = map_feat; a.map_feat_stride = broadcast ? 0 : 256;
+    a.curr_states = curr_states; a.cond_out = cond_feat; a.map_feat_out = nullptr; a.B = B;
+    HIPCK(h, launch_context_head(a, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
 int cld_compute_reward(cld_handle h, const float* traj, const float* traj_scaled, const float* raster_from_agent,
                        const uint8_t* drivable_map, int32_t H, int32_t W, const float* other_pos, const uint8_t* other_avail,
                        int32_t S, int32_t T_other, float collision_thresh, float* reward, float* offroad, float* collision,

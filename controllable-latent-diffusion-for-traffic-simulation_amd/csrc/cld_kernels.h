@@ -154,6 +154,8 @@ struct ContextHeadArgs {
     const float* curr_states;   // [B,4]
     float* cond_out;            // [B,256]
     float* map_feat_out;        // [B,256] or null (diagnostic tap: the fc output)
+    const float* map_feat_in;   // or null: skip pool + fc and take the map feature from here, row b at b * map_feat_stride
+    int map_feat_stride;        // 256, or 0 to broadcast one row to every agent
     int B;
     const float *fc_wt, *fc_b;  // transposed weights [in][out] throughout
     const float *s_wt[3], *s_b[3], *s_g[2], *s_be[2];     // agent_state_encoder: 4 -> 64 -> 64 -> 64

@@ -529,16 +529,18 @@ __global__ __launch_bounds__(256) void context_head_kernel(const ContextHeadArgs
     const int b0 = blockIdx.x * 4;
 
     // avg-pool over the 49 pixels of layer4's output [B,7,7,512] (adaptive_avg_pool2d((1,1)))
+    if (!a.map_feat_in) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int b = b0 + g;
+        for (int g = 0; g < 4; ++g) {
+            const int b = b0 + g;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int ch = tid + 256 * k;
-            float s = 0.f;
-            if (b < a.B)
-                for (int px = 0; px < 49; ++px) s += a.feat[((size_t)b * 49 + px) * 512 + ch];
-            pooled[g][ch] = s * (1.0f / 49.0f);
+            for (int k = 0; k < 2; ++k) {
+                const int ch = tid + 256 * k;
+                float s = 0.f;
+                if (b < a.B)
+                    for (int px = 0; px < 49; ++px) s += a.feat[((size_t)b * 49 + px) * 512 + ch];
+                pooled[g][ch] = s * (1.0f / 49.0f);
+            }
         }
     }
     // current states -> bufB[g][0..3]
@@ -548,8 +550,14 @@ __global__ __launch_bounds__(256) void context_head_kernel(const ContextHeadArgs
     }
     __syncthreads();
 
-    // map branch: fc 512 -> 256 (the 'map_model.fc' node: no output activation)
-    {
+    // map branch: fc 512 -> 256 (the 'map_model.fc' node: no output activation), or a map feature handed in
+    if (a.map_feat_in) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int b = (b0 + g < a.B) ? b0 + g : a.B - 1;
+            bufA[g][64 + tid] = a.map_feat_in[(size_t)b * a.map_feat_stride + tid];
+        }
+    } else {
         float v[4][1];
         linear_4<1>(&pooled[0][0], 512, 512, a.fc_wt, a.fc_b, 256, v, tid);
         put_4<1>(&bufA[0][0], 320, 64, 256, v, tid);

@@ -60,6 +60,7 @@ class Engine:
             raise CldError(f"cld_create failed ({rc})")
         self._ws = None
         self._ctx_ws = None
+        self._nc_map_feat = {}
         self._finalized = False
         self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[int(self.lib.cld_get_precision(self._h))]
         n = self.n_timesteps
@@ -313,6 +314,24 @@ class Engine:
                                                     C.c_void_p(self._ctx_ws.data_ptr()), C.c_size_t(self._ctx_ws.numel()),
                                                     self._stream()), "cld_context_encode")
         return (cond, mf) if want_map_feat else cond
+
+    def non_cond_feat(self, curr_states, cond_fill_value: float = -1.0):
+        """Unconditional features of classifier-free guidance (upstream diffuser.py:390-411,459-471): the combine MLP on
+        [state features | map features of a raster filled with `cond_fill_value`].  The filled raster is the same for every
+        agent, so its map feature is computed once per fill value and broadcast."""
+        cs = self._f32(curr_states)
+        B = cs.shape[0]
+        cs = self._f32(cs, (B, 4))
+        key = float(cond_fill_value)
+        if key not in self._nc_map_feat:
+            img = torch.full((1, 34, 224, 224), key, dtype=torch.float32, device=self.device)
+            _, mf = self.context_encode(img, torch.zeros(1, 4, device=self.device), want_map_feat=True)
+            self._nc_map_feat[key] = mf
+        out = torch.empty(B, COND, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_context_combine(self._h, _ptr(self._nc_map_feat[key]), 1, _ptr(cs), _ptr(out), B, self._stream()),
+                        "cld_context_combine")
+        return out
 
     def compute_reward(self, traj, traj_scaled, raster_from_agent, drivable_map, other_pos=None, other_avail=None,
                        collision_thresh: float = 0.8):

@@ -71,7 +71,9 @@ class CldPolicy:
         if "cond_feat" in obs_dict:
             aux = obs_dict
         else:                                                       # obs -> aux_info (vae_model.py:84-88 pre_vae)
-            aux = (self.context_encoder or self.vae.context_encoder)(obs_dict)
+            enc = self.context_encoder or self.vae.context_encoder
+            aux = enc(obs_dict, include_class_free_cond=True) if class_free_guide_w != 0.0 and enc is self.vae.context_encoder \
+                else enc(obs_dict)
         cond, cs = aux["cond_feat"], aux["curr_states"]
         B, N = cond.shape[0], int(num_action_samples)
         out = self.dm({"history_positions": cond}, {k: aux[k] for k in ("cond_feat", "curr_states", "non_cond_feat") if k in aux},

@@ -239,6 +239,13 @@ size_t cld_context_workspace_bytes(cld_handle h, int32_t B);
 int cld_context_encode(cld_handle h, const float* image, const float* curr_states, float* cond_feat, float* map_feat,
                        int32_t B, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The state branch and the combine MLP of ContextEncoder.forward on a map feature that is already known:
+ * cond = process_cond_mlp([agent_state_encoder(curr_states) | map_feat]).  Serves classifier-free guidance: upstream's
+ * unconditional features (src/tbsim/models/diffuser.py:390-411,459-471) are exactly this with the map feature of a raster
+ * filled with -1, which is the same row for every agent (broadcast != 0: map_feat is [1,256]; else [B,256]). */
+int cld_context_combine(cld_handle h, const float* map_feat, int32_t broadcast, const float* curr_states, float* cond_feat,
+                        int32_t B, void* stream);
+
 /* PPO reward of the reference (models/rl/criticmodel.py:7-64), per agent:
  *   offroad   = -#timesteps whose position, mapped to the raster with raster_from_agent (transform_points_tensor, :88-112),
  *               rounded (half to even) and clamped, falls on a non-drivable pixel of drivable_map                  (:13-29)

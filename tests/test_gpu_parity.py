@@ -585,3 +585,23 @@ def test_policy_guidance_from_upstream_config(eng10):
     pol.clear_guidance()
     act0, _ = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise)
     assert not torch.equal(act0.positions, act.positions)
+
+
+def test_non_cond_feat_for_classifier_free_guidance(eng_ctx):
+    """aux_info['non_cond_feat'] as upstream builds it (diffuser.py:390-411,459-471): the combine MLP on the agent's own state
+    features and the map features of a raster filled with -1 -- against the oracle run on that raster, and equal to a full
+    context_encode of the filled raster."""
+    from cld_amd.context_utils import ContextEncoder
+    from oracle import cld_oracle as O
+    B = 5
+    batch = {"history_positions": torch.zeros(B, 31, 2), "history_yaws": torch.zeros(B, 31, 1),
+             "curr_speed": torch.from_numpy(synth.uniform(8, "curr_speed", (B,), 0.0, 15.0)),
+             "image": torch.from_numpy(synth.make_raster(B, 8)).cuda()}
+    aux = ContextEncoder(eng_ctx)(batch, include_class_free_cond=True)
+    assert aux["non_cond_feat"].shape == (B, 256)
+    filled = torch.full((B, 34, 224, 224), -1.0)
+    full = eng_ctx.context_encode(filled.cuda(), aux["curr_states"])
+    assert (aux["non_cond_feat"] - full).abs().max().item() <= 1e-5
+    ref = O.context_encode(O.to_torch(synth.make_context_weights(0)), filled[:1].expand(B, -1, -1, -1), aux["curr_states"].cpu())
+    assert (aux["non_cond_feat"].cpu() - ref).abs().max().item() <= 1e-4
+    assert (aux["non_cond_feat"] - aux["cond_feat"]).abs().max().item() > 1e-2
