@@ -38,7 +38,8 @@ class CldGuidance(C.Structure):
                 ("lr", C.c_float), ("perturb_th", C.c_float), ("optimizer", C.c_int32),
                 ("speed_limit", C.c_float), ("acc_limit", C.c_float),
                 ("speed_limit_scale", C.c_void_p), ("acc_limit_scale", C.c_void_p),
-                ("target_pos", C.c_void_p), ("target_time", C.c_void_p), ("target_pos_scale", C.c_void_p)]
+                ("target_pos", C.c_void_p), ("target_time", C.c_void_p), ("target_pos_scale", C.c_void_p),
+                ("ext_grad", C.c_void_p)]
 
 
 _P = C.c_void_p

@@ -914,7 +914,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal n_timesteps (the reference sampler has stride 1)");
     if (gd) {
         if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
-        if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale))
+        if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad))
             return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
         if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
         if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, std::string(fn) + ": target_pos_scale needs target_pos and target_time");
@@ -958,6 +958,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
             g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
             g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
             g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
+            g.ext_grad = gd->ext_grad;
             g.scratch = w.guide; g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
             g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
             HIPCK(h, launch_guide(h->dec, h->dyn, g, s));
@@ -993,7 +994,7 @@ int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const 
     int rc = check_common(h, "cld_guidance_step", B, 0, workspace, workspace_bytes);
     if (rc) return rc;
     if (!h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_guidance_step: decoder weights not loaded");
-    if (!mean || !cond || !gd || !gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale) ||
+    if (!mean || !cond || !gd || !gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad) ||
         (x_next && sigma != 0.f && !z))
         return fail(h, CLD_ERR_ARG, "cld_guidance_step: null pointer");
     if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, "cld_guidance_step: unknown optimizer");
@@ -1004,6 +1005,7 @@ int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const 
     g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
     g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
     g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
+    g.ext_grad = gd->ext_grad;
     g.z = z; g.mean_out = mean_guided; g.x_out = x_next; g.grad_out = grad; g.scratch = w.guide;
     g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
     g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B;

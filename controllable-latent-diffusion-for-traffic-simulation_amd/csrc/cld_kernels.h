@@ -176,6 +176,7 @@ struct GuideArgs {
     const float* target_pos;          // [B,2] waypoint in the agent frame, or null
     const int* target_time;           // [B] index (0..51) of the trajectory state that should hit it
     const float* target_pos_scale;    // [B] or null (term off): weight of |pos[target_time] - target_pos|
+    const float* ext_grad;            // [B,52,6] or null: dL/dtraj of a loss evaluated elsewhere on the descaled trajectory
     const float* z;             // [B,52,4] N(0,1) draw or null (on-device generator)
     float* mean_out;            // guided mean [B,52,4] or null
     float* x_out;               // guided mean + sigma z, [>=B,52,4] or null

@@ -35,6 +35,9 @@ constexpr int GT = 52;
 //     + s_al * sum_t relu(|acc_t| - acc_limit)                   AccLimitLoss         :1444-1467 (unclipped descaled action)
 //     + s_tp * |(x, y)_{T*+1} - target_pos|                      TargetPosAtTimeLoss  :632-670   (target_time = T* >= 0)
 //       or s_tp * mean_{t >= m} softmin_t(dist) dist_t^2           TargetPosLoss        :672-716   (target_time = -(m + 1) < 0)
+//     + sum_t <ext_grad[b, t, :], (x, y, v, yaw, acc, yaw-rate)_t>      any loss computed elsewhere on the decoded trajectory
+//       (ext_grad = dL/dtraj of the descaled [B,52,6] trajectory: this makes the kernel the vector-Jacobian product of
+//        decoder + roll-out, so every upstream guidance loss that is torch code on the trajectory can drive it)
 // act0 / act1 [t * st] in; dact0 / dact1 [t] = dL / d act out.  min / max / clamp pass gradients like torch (clamp: on
 // [lo, hi]; an active bound of the yaw-rate clip routes the gradient into yb and from there into v_k).
 // sc: 6 x 54 floats of per-agent scratch (v_k, th_k, dL/dv_k, clip mask of v_k, dL/dx_k, dL/dy_k).
@@ -48,14 +51,15 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
     const float s_sl = a.speed_limit_scale ? a.speed_limit_scale[b] : 0.f;
     const float s_al = a.acc_limit_scale ? a.acc_limit_scale[b] : 0.f;
     const float s_tp = a.target_pos_scale ? a.target_pos_scale[b] : 0.f;
-    const bool pos = s_tp != 0.f;
+    const float* eg = a.ext_grad ? a.ext_grad + (size_t)b * GT * 6 : nullptr;
+    const bool pos = s_tp != 0.f || eg != nullptr;
     // ---- forward ----
     float v_raw = cs[2], x = cs[0], y = cs[1], yaw = cs[3];
     vk[0] = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
     th[0] = yaw;
     gv[0] = 0.f;
     int tstar = 0;
-    if (pos) { tstar = a.target_time[b]; tstar = tstar > GT - 1 ? GT - 1 : tstar; }
+    if (s_tp != 0.f) { tstar = a.target_time[b]; tstar = tstar > GT - 1 ? GT - 1 : tstar; }    // (target_* are null without the term)
     for (int t = 0; t < GT; ++t) {
         const float acc = act0[t * st] * d.std[4] + d.mean[4];
         v_raw += fminf(fmaxf(acc, d.acc_lo), d.acc_hi) * d.dt;
@@ -68,6 +72,7 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
             g += s_ts * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));        // d|x|/dx, 0 at 0 (and for NaN targets: nan_to_num)
         }
         if (s_sl != 0.f && fabsf(v) - a.speed_limit > 0.f) g += s_sl * ((v > 0.f) ? 1.f : -1.f);
+        if (eg) g += eg[t * 6 + 2];
         gv[t + 1] = g;                          // direct loss terms on v_{t+1}; the clip mask is applied in the backward sweep
         gth[t + 1] = vok ? 1.f : 0.f;           // (borrowed until the backward sweep: clip mask of v_{t+1})
         if (pos) {
@@ -83,7 +88,9 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
             gxk[t] = x; gyk[t] = y;             // positions for now
         }
     }
-    if (pos) {      // positions -> direct position gradients
+    if (pos && s_tp == 0.f) {
+        for (int t = 0; t < GT; ++t) { gxk[t] = 0.f; gyk[t] = 0.f; }
+    } else if (pos) {      // positions -> direct position gradients
         const float wx = a.target_pos[2 * b], wy = a.target_pos[2 * b + 1];
         if (tstar >= 0) {                       // hit the waypoint AT step tstar: d|e|/de (torch.norm: 0 at 0)
             const float ex = gxk[tstar] - wx, ey = gyk[tstar] - wy;
@@ -125,6 +132,7 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
         float d_w = 0.f, d_vk_from_yb = 0.f, d_vbar = 0.f;
         if (pos) {
             gx += gxk[k]; gy += gyk[k];
+            if (eg) { gx += eg[k * 6 + 0]; gy += eg[k * 6 + 1]; g_th_suffix += eg[k * 6 + 3]; }     // direct terms on x_{k+1}, y_{k+1}, th_{k+1}
             float sn, cn;
             sincosf(th[k], &sn, &cn);
             const float vbar = 0.5f * (vk[k] + vk[k + 1]);
@@ -138,6 +146,7 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
             const float wr = act1[k * st] * d.std[5] + d.mean[5];
             float d_yb = 0.f;
             if (wr > yb) d_yb = d_wc; else if (wr < -yb) d_yb = -d_wc; else d_w = d_wc;
+            if (eg) d_w += eg[k * 6 + 5];                                          // the trajectory carries the unclipped descaled yaw rate
             if (d_yb != 0.f && fminf(ya, ybb) > 0.1f) {                           // the 0.1 floor is not active
                 const float dyb_dav = (ya < ybb) ? d.max_steer : ((av > 0.1f) ? -d.max_yawvel / (av * av) : 0.f);
                 d_vk_from_yb = d_yb * dyb_dav * ((vk[k] > 0.f) ? 1.f : ((vk[k] < 0.f) ? -1.f : 0.f));
@@ -151,6 +160,7 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
         const float acc = act0[k * st] * d.std[4] + d.mean[4];
         float g = (acc >= d.acc_lo && acc <= d.acc_hi) ? run_v * d.dt : 0.f;
         if (s_al != 0.f && fabsf(acc) - a.acc_limit > 0.f) g += s_al * ((acc > 0.f) ? 1.f : -1.f);
+        if (eg) g += eg[k * 6 + 4];                                                // ... and the unclipped descaled acceleration
         dact0[k] = g * d.std[4];
         dact1[k] = d_w * d.std[5];
         gv[k] += d_vk_from_yb;                  // v_k is v_prev of step k (k >= 1: a parameter-dependent speed)

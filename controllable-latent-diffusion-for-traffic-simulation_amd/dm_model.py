@@ -107,7 +107,18 @@ class DmModel:
     # ---- dm_model.py:98-142 ------------------------------------------------------------
     @torch.no_grad()
     def forward(self, data_batch, aux_info, algo_config, noise: Optional[Mapping] = None, seed: int = 0,
-                class_free_guide_w: float = 0.0, guidance: Optional[Mapping] = None):
+                class_free_guide_w: float = 0.0, guidance: Optional[Mapping] = None, guidance_fn=None, **guidance_opt):
+        """`guidance_fn(traj [BN,52,6]) -> scalar` is a caller-defined torch loss on the decoded trajectories (e.g. one of
+        upstream's guidance losses); it takes the place of the built-in losses (`guidance=`) through `Engine.sample_with_loss`
+        (`guidance_opt`: lr / optimizer / perturb_th).  Needs `noise=` and aux_info['curr_states']."""
+        if guidance_fn is not None:
+            num_samp = int(cfg_get(algo_config, "num_samp", 1))
+            aux = repeat_by_expand_at(aux_info, repeats=num_samp, dim=0)
+            if noise is None:
+                BN = aux["cond_feat"].shape[0]
+                noise = {"x_T": torch.randn(BN, 52, 4, device=self.device), "noise": torch.randn(self.n_timesteps, BN, 52, 4, device=self.device)}
+            x0, x1 = self.engine.sample_with_loss(noise["x_T"], aux["cond_feat"], aux["curr_states"], noise["noise"], guidance_fn, **guidance_opt)
+            return {"pred_traj": x0, "x1": x1, "log_prob_final": None, "aux_info": aux}
         return self.sample_traj(data_batch, algo_config, aux_info, noise=noise, seed=seed,
                                 class_free_guide_w=class_free_guide_w, guidance=guidance)
 

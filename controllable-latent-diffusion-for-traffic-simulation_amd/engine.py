@@ -160,6 +160,7 @@ class Engine:
             return float(lim), sc
         sl, sls = term("speed_limit")
         al, als = term("acc_limit")
+        eg = None if g.get("ext_grad") is None else self._f32(g["ext_grad"], (B, T, 6))
         tp = tt = tps = None
         if g.get("target_pos") is not None:      # (positions [B,2], time index [B], per-agent scale [B] | scalar weight): TargetPosAtTimeLoss
             pos_, time_, sc = g["target_pos"]
@@ -177,8 +178,8 @@ class Engine:
                               -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
                               sl, al, None if sls is None else sls.data_ptr(), None if als is None else als.data_ptr(),
                               None if tp is None else tp.data_ptr(), None if tt is None else tt.data_ptr(),
-                              None if tps is None else tps.data_ptr())
-        return cg, (cs, ts, ls, sls, als, tp, tt, tps)
+                              None if tps is None else tps.data_ptr(), None if eg is None else eg.data_ptr())
+        return cg, (cs, ts, ls, sls, als, tp, tt, tps, eg)
 
     def guidance_step(self, mean, cond, guidance: Mapping, sigma: float, z=None, want_grad=False):
         """One guidance step on a posterior mean [B,52,4] (upstream PerturbationGuidance.perturb, guidance_loss.py:2221-2282)
@@ -197,6 +198,45 @@ class Engine:
                                                    _ptr(mg), _ptr(xn), _ptr(gr), B, ws, wsn, self._stream()), "cld_guidance_step")
         out = (mg,) + ((xn,) if z is not None else ()) + ((gr,) if want_grad else ())
         return out[0] if len(out) == 1 else out
+
+    def decode_vjp(self, z, cond, curr_states, grad_traj):
+        """Vector-Jacobian product of `decode` (LSTM decoder + descale + unicycle roll-out, descaled output): grad_traj
+        [B,52,6] = dL/dtraj -> dL/dz [B,52,4].  With it any loss evaluated on decoded trajectories (torch autograd over
+        upstream's guidance losses included) can be pulled back to the latent."""
+        z = self._f32(z)
+        B = z.shape[0]
+        gd = {"curr_states": curr_states, "ext_grad": grad_traj, "lr": 1.0, "optimizer": "sgd"}
+        _, grad = self.guidance_step(z, cond, gd, sigma=0.0, want_grad=True)
+        return grad
+
+    def sample_with_loss(self, x_T, cond, curr_states, noise, loss_fn, lr: Optional[float] = 0.3, optimizer: str = "adam",
+                         perturb_th=None):
+        """Ancestral loop with a CALLER-DEFINED guidance loss: `loss_fn(traj [B,52,6] descaled) -> scalar` is torch code
+        (e.g. upstream's guidance losses, `src/tbsim/utils/guidance_loss.py`, which couple agents or sample rasters).  Per
+        step t > 0: U-Net + posterior mean (HIP), decode the mean (HIP), dL/dtraj by torch autograd over `loss_fn` only,
+        then decoder + roll-out backward, the optimiser step and the noise add (HIP, `cld_guidance_step` with `ext_grad`).
+        Same semantics as `sample(..., guidance=)` (upstream diffuser.py:844-929); slower, because the loop is driven from
+        Python.  `noise` [steps,B,52,4] is required.  -> (x0, x1)."""
+        x = self._f32(x_T)
+        B = x.shape[0]
+        cond = self._f32(cond, (B, COND)); cs = self._f32(curr_states, (B, 4))
+        n = self.n_timesteps
+        noise = self._f32(noise, (n, B, T, D))
+        x1 = None
+        for it in range(n):
+            i = n - 1 - it
+            xn, mean, sigma = self.ddpm_step(x, cond, i, noise[it])
+            if i == 0:
+                x = xn
+                break
+            traj = self.decode(mean, cond, cs, descaled_output=True).requires_grad_(True)
+            with torch.enable_grad():
+                (gtraj,) = torch.autograd.grad(loss_fn(traj), traj)
+            gd = {"curr_states": cs, "ext_grad": gtraj, "lr": lr, "perturb_th": perturb_th, "optimizer": optimizer}
+            _, x = self.guidance_step(mean, cond, gd, sigma, z=noise[it])
+            if i == 1:
+                x1 = x.clone()
+        return x, x1
 
     def sample(self, x_T, cond, noise=None, seed: int = 0, want_x1=True, want_logp=True,
                non_cond=None, guidance_w: float = 0.0, guidance: Optional[Mapping] = None):

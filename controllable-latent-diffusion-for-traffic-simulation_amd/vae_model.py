@@ -92,3 +92,22 @@ class VaeModel:
     def descale_traj(self, traj, chosen_inds=()):
         inds = list(chosen_inds) or self.default_chosen_inds      # x * std + mean, vae_model.py:170
         return traj * self.div_coeffs[inds].to(traj.device) + self.add_coeffs[inds].to(traj.device)
+
+
+class DecodeFn(torch.autograd.Function):
+    """`traj = DecodeFn.apply(z, cond, curr_states, engine)`: the decode chain (lstm_dec -> descale -> unicycle roll-out,
+    descaled [B,52,6]) as a differentiable torch op whose backward is the HIP vector-Jacobian product `Engine.decode_vjp`.
+    Upstream's guidance losses (`src/tbsim/utils/guidance_loss.py`) are torch code on exactly this trajectory, so they can be
+    evaluated with autograd on the decoded output and pulled back to the latent without any CPU or torch fallback of the
+    path itself.  Gradients flow to `z` only."""
+
+    @staticmethod
+    def forward(ctx, z, cond, curr_states, engine):
+        ctx.engine = engine
+        ctx.save_for_backward(z.detach(), cond.detach(), curr_states.detach())
+        return engine.decode(z.detach(), cond, curr_states, descaled_output=True)
+
+    @staticmethod
+    def backward(ctx, grad_traj):
+        z, cond, cs = ctx.saved_tensors
+        return ctx.engine.decode_vjp(z, cond, cs, grad_traj.contiguous()), None, None, None

@@ -177,6 +177,11 @@ typedef struct cld_guidance {
                                         *     < 0: TargetPosLoss (:672-716) instead -- hit it at SOME state >= m = -(value + 1):
                                         *          target_pos_scale[b] * mean_{t >= m} softmin_t(dist) * dist_t^2 */
     const float* target_pos_scale;     /* [B] or NULL */
+    /* Any other loss: ext_grad [B,52,6] = dL/dtraj on the DESCALED trajectory (x, y, v, yaw, acc, yaw-rate) that cld_decode
+     * returns for this mean -- e.g. from autograd over upstream's own guidance losses (agent / map collision, ...), which
+     * are torch code on that trajectory.  The step then uses J^T ext_grad, J = d traj / d mean (decoder + roll-out); with
+     * cld_guidance_step(..., grad) this is the vector-Jacobian product itself.  NULL = no such term. */
+    const float* ext_grad;
 } cld_guidance;
 
 /* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */

@@ -154,11 +154,11 @@ def test_guidance_struct_matches_header():
     g = _lib.CldGuidance
     assert [n for n, _ in g._fields_] == ["curr_states", "target_speed", "loss_scale", "lr", "perturb_th", "optimizer",
                                           "speed_limit", "acc_limit", "speed_limit_scale", "acc_limit_scale",
-                                          "target_pos", "target_time", "target_pos_scale"]
-    assert ctypes.sizeof(g) == 88 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
+                                          "target_pos", "target_time", "target_pos_scale", "ext_grad"]
+    assert ctypes.sizeof(g) == 96 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
     hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
     body = hdr[hdr.index("typedef struct cld_guidance {"):hdr.index("} cld_guidance;")]
-    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale);", body)] == [n for n, _ in g._fields_]
+    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad);", body)] == [n for n, _ in g._fields_]
 
 
 def test_timers_keep_the_reference_surface():
