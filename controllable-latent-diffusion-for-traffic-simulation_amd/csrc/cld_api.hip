@@ -47,6 +47,7 @@ const char* const kResnet = "context_encoder.map_encoder.encoder_heads.map_model
 
 struct cld_handle_s {
     cld_config cfg{};
+    int stride = 1;                                  // DmModel.stride (dm_model.py:25,119): the loop visits i = ..., 2 stride, stride, 0
     int precision = CLD_PRECISION_F32;               // cfg.precision, possibly overridden by CLD_PRECISION (experiments)
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
@@ -408,6 +409,9 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     return hipSuccess;
 }
 
+// loop iterations of the sampler: len(range(0, n_timesteps, stride)) (dm_model.py:119)
+inline int loop_steps(cld_handle h) { return (h->cfg.n_timesteps + h->stride - 1) / h->stride; }
+
 const std::vector<float>* getw(cld_handle h, const std::string& k) {
     auto it = h->w.find(k);
     return it == h->w.end() ? nullptr : &it->second;
@@ -464,6 +468,12 @@ int cld_debug_stamps(cld_handle h, void* buf, int32_t layer) {
     if (!h) return CLD_ERR_ARG;
     h->stamp_buf = static_cast<unsigned long long*>(buf);
     h->stamp_layer = layer;
+    return CLD_OK;
+}
+
+int cld_set_stride(cld_handle h, int32_t stride) {
+    if (!h || stride < 1 || stride > h->cfg.n_timesteps) return fail(h, CLD_ERR_ARG, "cld_set_stride: stride out of range");
+    h->stride = stride;
     return CLD_OK;
 }
 
@@ -874,15 +884,15 @@ int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* 
     int rc = check_common(h, "cld_sample", B, 0, workspace, workspace_bytes);
     if (rc) return rc;
     if (!x_T || !cond) return fail(h, CLD_ERR_ARG, "cld_sample: null pointer");
-    if (steps != h->cfg.n_timesteps)
-        return fail(h, CLD_ERR_ARG, "cld_sample: steps must equal n_timesteps (the reference sampler has stride 1)");
+    if (steps != loop_steps(h))
+        return fail(h, CLD_ERR_ARG, "cld_sample: steps must equal len(range(0, n_timesteps, stride)) = " + std::to_string(loop_steps(h)));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int bp = pad16(B);
     Ws w = carve(workspace, bp);
     HIPCK(h, launch_pack_latent(x_T, w.xw, B, bp, s));
     HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
     for (int it = 0; it < steps; ++it) {
-        const int i = steps - 1 - it;
+        const int i = (steps - 1 - it) * h->stride;
         HIPCK(h, run_unet(h, w, w.xw, i, bp, s));
         const float sigma = std::exp(0.5f * h->plvc[i]);
         HeadArgs a{};
@@ -910,8 +920,8 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
     int rc = check_common(h, fn, cfg ? 2 * pad16(B) : B, 0, workspace, workspace_bytes);
     if (rc) return rc;
     if (!x_T || !cond) return fail(h, CLD_ERR_ARG, std::string(fn) + ": null pointer");
-    if (steps != h->cfg.n_timesteps)
-        return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal n_timesteps (the reference sampler has stride 1)");
+    if (steps != loop_steps(h))
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal len(range(0, n_timesteps, stride)) = " + std::to_string(loop_steps(h)));
     if (gd) {
         if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
         if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad))
@@ -932,7 +942,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
         HIPCK(h, launch_cond_bias(non_cond, h->wc, h->cbias_b, w.cb + (size_t)bp * NCB, B, bp, NCB, s));
     }
     for (int it = 0; it < steps; ++it) {
-        const int i = steps - 1 - it;
+        const int i = (steps - 1 - it) * h->stride;
         HIPCK(h, run_unet(h, w, w.xw, i, bpn, s));
         const float sigma = std::exp(0.5f * h->plvc[i]);
         const bool guide = gd && i > 0;       // upstream defaults: apply_guidance_intermediate, not apply_guidance_output

@@ -74,7 +74,6 @@ class DmModel:
     def __init__(self, algo_config=None, modality_shapes=None, n_timesteps: int = 100, device="cuda:0",
                  engine: Optional[Engine] = None):
         self.n_timesteps = int(n_timesteps)
-        self.stride = 1
         self.horizon = cfg_get(algo_config, "horizon", 52)
         self.dt = cfg_get(algo_config, "step_time", 0.1)
         if self.horizon != 52 or cfg_get(algo_config, "vae.latent_size", 4) != 4 or \
@@ -88,6 +87,14 @@ class DmModel:
         self.model = _UnetSurface(self.engine)
         for name in ("x_t_cof", "noise_cof", "posterior_log_variance_clipped"):
             setattr(self, name, torch.from_numpy(getattr(self.engine, name)).to(self.device))
+
+    @property
+    def stride(self) -> int:            # dm_model.py:25 -- a plain attribute in the reference; here it also reaches the engine
+        return self.engine.stride
+
+    @stride.setter
+    def stride(self, value: int):
+        self.engine.set_stride(value)
 
     # nn.Module-compatible conveniences used by the callers
     def load_state_dict(self, sd, strict=True):
@@ -136,7 +143,7 @@ class DmModel:
             x_T, z = noise["x_T"], noise.get("noise")
         else:   # same draw count as the reference (one for x_T, one per step), from torch's device generator
             x_T = torch.randn(BN, 52, 4, device=self.device)
-            z = torch.randn(self.n_timesteps, BN, 52, 4, device=self.device)
+            z = torch.randn(self.engine.loop_steps, BN, 52, 4, device=self.device)
         x_T = torch.as_tensor(x_T).reshape(BN, 52, 4)
         if guidance is not None:
             guidance = dict(guidance)

@@ -53,6 +53,7 @@ class Engine:
                 cfg.norm_std[i] = float(norm_info[1][i])
         self.cfg = cfg
         self.n_timesteps = int(n_timesteps)
+        self.stride = 1
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = self.lib.cld_create(C.byref(cfg), C.byref(self._h))
@@ -96,6 +97,15 @@ class Engine:
                 self._h = None
         except Exception:
             pass
+
+    def set_stride(self, stride: int):
+        """DmModel.stride (dm_model.py:25,119): the sampling loop visits i in reversed(range(0, n_timesteps, stride))."""
+        self._check(self.lib.cld_set_stride(self._h, int(stride)), "cld_set_stride")
+        self.stride = int(stride)
+
+    @property
+    def loop_steps(self) -> int:
+        return len(range(0, self.n_timesteps, self.stride))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd: Mapping, strict: bool = True):
@@ -220,11 +230,11 @@ class Engine:
         x = self._f32(x_T)
         B = x.shape[0]
         cond = self._f32(cond, (B, COND)); cs = self._f32(curr_states, (B, 4))
-        n = self.n_timesteps
+        n = self.loop_steps
         noise = self._f32(noise, (n, B, T, D))
         x1 = None
         for it in range(n):
-            i = n - 1 - it
+            i = (n - 1 - it) * self.stride
             xn, mean, sigma = self.ddpm_step(x, cond, i, noise[it])
             if i == 0:
                 x = xn
@@ -247,10 +257,10 @@ class Engine:
         x_T = self._f32(x_T)
         B = x_T.shape[0]
         x_T = self._f32(x_T, (B, T, D)); cond = self._f32(cond, (B, COND))
-        n = self.n_timesteps
+        n = self.loop_steps                 # loop iterations = noise slabs (n_timesteps with the reference's stride 1)
         noise = None if noise is None else self._f32(noise, (n, B, T, D))
         x0 = torch.empty_like(x_T)
-        x1 = torch.empty_like(x_T) if want_x1 else None
+        x1 = torch.empty_like(x_T) if (want_x1 and self.stride == 1) else None      # step 1 is only visited with stride 1
         logp = torch.empty(B, dtype=torch.float32, device=self.device) if want_logp else None
         cfg = non_cond is not None and guidance_w != 0.0
         with torch.cuda.device(self.device):

@@ -116,9 +116,14 @@ int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx
                   float* x_next, float* mean, float* sigma_host /*HOST*/, int32_t B,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* DmModel.stride (dm_model.py:25: 1; the loop of :119 visits i in reversed(range(0, n_timesteps, stride))).  Default 1. */
+int cld_set_stride(cld_handle h, int32_t stride);
+
 /* out = DmModel.forward(...)/sample_traj  (dm_model.py:98-142): the full ancestral
- * loop i = steps-1 .. 0 (steps must equal n_timesteps; the reference has stride 1).
- * x_T [B,52,4]; noise [steps,B,52,4], slab s feeds loop iteration s (i = steps-1-s),
+ * loop over i in reversed(range(0, n_timesteps, stride)); `steps` must equal the number of those iterations
+ * (n_timesteps with the reference's stride 1).  With stride > 1 step 1 is never visited and x1 is left untouched (the
+ * reference returns None).
+ * x_T [B,52,4]; noise [steps,B,52,4], slab s feeds loop iteration s (i = (steps-1-s) * stride),
  * the reference RNG order (one randn_like per step incl. the masked t=0 one); if
  * noise == NULL a counter-based on-device generator seeded with `seed` is used
  * (throughput runs; not parity-comparable with torch's RNG).

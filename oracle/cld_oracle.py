@@ -168,14 +168,14 @@ def normal_log_prob_mean(x: Tensor, mean: Tensor, sigma: Tensor) -> Tensor:
     return lp.mean(dim=(1, 2))
 
 
-def sample(w, sched, x_T: Tensor, noise: Tensor, cond: Tensor, n_steps: Optional[int] = None) -> dict:
-    """dm_model.py:103-142 -- loop i = n-1..0; noise[s] feeds iteration s (i = n-1-s).
-    Returns pred_traj (x0), x1, log_prob_final."""
+def sample(w, sched, x_T: Tensor, noise: Tensor, cond: Tensor, n_steps: Optional[int] = None, stride: int = 1) -> dict:
+    """dm_model.py:103-142 -- loop over i in reversed(range(0, n, stride)) (:119; stride = 1 in the reference's ctor, :25);
+    noise[s] feeds iteration s.  Returns pred_traj (x0), x1 (None unless step 1 is visited), log_prob_final."""
     n = int(sched["x_t_cof"].shape[0]) if n_steps is None else n_steps
     x = x_T
     x1 = None
     out = {}
-    for s, i in enumerate(reversed(range(n))):
+    for s, i in enumerate(reversed(range(0, n, stride))):
         x, mean, sigma = ddpm_step(w, sched, x, cond, i, noise[s])
         if i == 1:
             x1 = x.clone()

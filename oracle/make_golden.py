@@ -264,6 +264,21 @@ def section_reward(ref):
          raster_points=pts, collision_reward=col, any_offroad=np.array(any_off, np.float32))
 
 
+def section_stride(ref):
+    """DmModel.stride (dm_model.py:25,119): the reference's own sampler with stride 4 on a 100-step schedule (25 iterations)."""
+    n, B, stride = 100, 8, 4
+    dm = build_dm(ref, n, True)
+    dm.stride = stride
+    inp = synth.make_inputs(B, IN_SEED)
+    nz = synth.make_noise(B, len(range(0, n, stride)), NOISE_SEED)
+    with torch.no_grad(), feed_noise([T(nz["x_T"])] + [T(z) for z in nz["noise"]]):
+        out = dm({"history_positions": torch.zeros(B, 31, 2)}, {"cond_feat": T(inp["cond_feat"])}, ref.algo)
+    assert out["x1"] is None
+    save("sample_n100_stride4", {"B": B, "n_timesteps": n, "stride": stride, "w_seed": W_SEED, "affine_jitter": True,
+                                 "in_seed": IN_SEED, "noise_seed": NOISE_SEED},
+         pred_traj=out["pred_traj"], log_prob_final=out["log_prob_final"])
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -271,13 +286,14 @@ def main():
     algo = ref.algo
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
-            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward}[name](ref)
+            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
     section_context(ref)
     section_guidance(ref)
     section_reward(ref)
+    section_stride(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

@@ -688,3 +688,25 @@ def test_sample_with_caller_defined_loss(eng10):
     other, _ = eng10.sample_with_loss(x_T, cond, cs, z, apart, lr=0.3)
     plain, _, _ = eng10.sample(x_T, cond, noise=z)
     assert bool(torch.isfinite(other).all()) and not torch.equal(other, plain)
+
+
+def test_sample_with_stride_golden(golden):
+    """DmModel.stride (the reference's attribute, dm_model.py:25,119): stride 4 on the 100-step schedule against the reference's
+    own sampler; x1 is None as in the reference; a wrong slab count is refused."""
+    from cld_amd._lib import CldError
+    from cld_amd.dm_model import DmModel
+    meta, g = golden("sample_n100_stride4")
+    B, n, st = meta["B"], meta["n_timesteps"], meta["stride"]
+    dm = DmModel(None, None, n_timesteps=n, engine=_engine(n, meta["affine_jitter"], decoder=False))
+    dm.stride = st
+    assert dm.stride == st and dm.engine.loop_steps == 25
+    nz = synth.make_noise(B, 25, meta["noise_seed"])
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"]).cuda()
+    out = dm({"history_positions": torch.zeros(B, 31, 2)}, {"cond_feat": cond}, {"num_samp": 1},
+             noise={"x_T": torch.from_numpy(nz["x_T"]), "noise": torch.from_numpy(nz["noise"])})
+    scale = float(np.abs(g["pred_traj"]).max())
+    assert out["x1"] is None
+    assert np.abs(out["pred_traj"].cpu().numpy() - g["pred_traj"]).max() <= 1e-3 * max(1.0, scale)
+    assert np.abs(out["log_prob_final"].cpu().numpy() - g["log_prob_final"]).max() <= 1e-4
+    with pytest.raises(CldError):
+        dm.engine.sample(torch.from_numpy(nz["x_T"]), cond, noise=torch.zeros(100, B, 52, 4))

@@ -268,3 +268,17 @@ def test_guidance_targetpos_softmin_vs_reference_perturb(golden):
     xg, _ = O.guidance_step(O.to_torch(synth.make_decoder_weights(meta["w_seed"])), mean, cond, cs, None, None, c["lr"], None, "sgd",
                             target_pos=(wp, wt, tps))
     assert np.abs(xg.numpy() - g["guided_targetpos_sgd"]).max() <= 2e-6
+
+
+def test_sample_with_stride_vs_reference(golden):
+    """DmModel.stride = 4 (dm_model.py:25,119): 25 iterations over i = 96, 92, ..., 0 recorded from the reference."""
+    meta, g = golden("sample_n100_stride4")
+    B, n, st = meta["B"], meta["n_timesteps"], meta["stride"]
+    w = W(meta["affine_jitter"])
+    nz = synth.make_noise(B, len(range(0, n, st)), meta["noise_seed"])
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    out = O.sample(w, O.schedule(n), torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"]), cond, stride=st)
+    scale = np.abs(g["pred_traj"]).max()
+    assert out["x1"] is None
+    assert np.abs(out["pred_traj"].numpy() - g["pred_traj"]).max() <= 1e-5 * max(1.0, scale)
+    assert np.abs(out["log_prob_final"].numpy() - g["log_prob_final"]).max() <= 1e-4
