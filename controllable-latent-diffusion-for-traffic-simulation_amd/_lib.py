@@ -54,6 +54,8 @@ SIGNATURES = {
     "cld_workspace_bytes": (C.c_size_t, [_P, C.c_int32]),
     "cld_get_schedule": (C.c_int, [_P, _P, _P, _P]),
     "cld_unet_forward": (C.c_int, [_P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "cld_unet_forward_t": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "cld_denoise_loss": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_ddpm_step": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.c_size_t, _P]),
     "cld_sample": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
     "cld_sample_cfg": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),

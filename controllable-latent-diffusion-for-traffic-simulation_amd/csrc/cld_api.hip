@@ -55,7 +55,8 @@ struct cld_handle_s {
     bool finalized = false, has_decoder = false;
     std::vector<void*> dev_allocs;
     // schedule (host, fp32 as in dm_model.py:29-56)
-    std::vector<float> x_t_cof, noise_cof, plvc;
+    std::vector<float> x_t_cof, noise_cof, plvc, sqrt_acp, sqrt_1m_acp;
+    float* qs_tab = nullptr;            // device [2][n_timesteps]: sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod) (q_sample, dm_model.py:91-96)
     // device-side model
     ResBlock blocks[12];
     ConvLayer down[2], upT[2][2], final_cb;
@@ -200,8 +201,10 @@ void build_schedule(cld_handle h) {
     float run = 1.0f;
     for (int i = 0; i < n; ++i) { acp_prev[i] = run; run = run * alphas[i]; acp[i] = run; }
     acp_prev[0] = 1.0f;
-    h->x_t_cof.resize(n); h->noise_cof.resize(n); h->plvc.resize(n);
+    h->x_t_cof.resize(n); h->noise_cof.resize(n); h->plvc.resize(n); h->sqrt_acp.resize(n); h->sqrt_1m_acp.resize(n);
     for (int i = 0; i < n; ++i) {
+        h->sqrt_acp[i] = std::sqrt(acp[i]);                 // dm_model.py:36-37
+        h->sqrt_1m_acp[i] = std::sqrt(1.0f - acp[i]);
         const float pv = betas[i] * (1.0f - acp_prev[i]) / (1.0f - acp[i]);
         h->plvc[i] = std::log(pv < 1e-20f ? 1e-20f : pv);
         h->x_t_cof[i] = std::sqrt(1.0f / alphas[i]);
@@ -307,7 +310,7 @@ ConvArgs make_args(cld_handle h, const ConvLayer& l, const float* x1, const floa
     ConvArgs a{};
     a.x1 = x1; a.x2 = x2; a.c1_real = l.c1_real; a.c1_pad = l.c1_pad; a.c2 = l.c2;
     a.wfrag = l.wfrag; a.bias = l.bias; a.gamma = l.gamma; a.beta = l.beta;
-    if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row + l.cb_off; }
+    if (l.cb_off >= 0) { a.cbias = cb + l.cb_off; a.cb_stride = NCB; a.tbias = tb_row ? tb_row + l.cb_off : nullptr; }
     a.res = res; a.y = y; a.c_out = l.c_out; a.ly = l.ly; a.off0 = l.off0; a.orow0 = l.orow0;
     a.wscale_inv = l.g.ain == 1 ? 1.0f / kWScale : 1.0f;
     a.stamps = nullptr;
@@ -362,7 +365,7 @@ hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const flo
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
 // final_conv.0 activations [b_pad,52,64] in w.buf[7].
 hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_pad, hipStream_t s) {
-    const float* tbr = h->tb + (size_t)t_idx * NCB;
+    const float* tbr = t_idx >= 0 ? h->tb + (size_t)t_idx * NCB : nullptr;     // < 0: per-agent timesteps, time bias folded into w.cb
     float* const* b = w.buf;
     h->launch_counter = 0;
     h->eval_counter++;
@@ -673,6 +676,11 @@ int cld_finalize(cld_handle h, void* stream) {
         }
         UP(h->tb, tb);
     }
+    {
+        std::vector<float> qs(h->sqrt_acp);
+        qs.insert(qs.end(), h->sqrt_1m_acp.begin(), h->sqrt_1m_acp.end());
+        UP(h->qs_tab, qs);
+    }
     UP(h->head_w, *getw(h, "model.final_conv.1.weight"));
     UP(h->head_b, *getw(h, "model.final_conv.1.bias"));
 
@@ -852,6 +860,44 @@ int cld_unet_forward(cld_handle h, const float* x, const float* cond, int32_t t_
     HeadArgs a{};
     a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
     HIPCK(h, launch_head(a, s));
+    return CLD_OK;
+}
+
+int cld_unet_forward_t(cld_handle h, const float* x, const float* cond, const int32_t* t_idx, float* eps, int32_t B,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_unet_forward_t", B, 0, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x || !cond || !t_idx || !eps) return fail(h, CLD_ERR_ARG, "cld_unet_forward_t: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(B);
+    Ws w = carve(workspace, bp);
+    HIPCK(h, launch_pack_latent(x, w.xw, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    HIPCK(h, launch_add_time_bias(w.cb, h->tb, t_idx, h->cfg.n_timesteps, B, NCB, s));
+    HIPCK(h, run_unet(h, w, w.xw, -1, bp, s));
+    HeadArgs a{};
+    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
+    HIPCK(h, launch_head(a, s));
+    return CLD_OK;
+}
+
+int cld_denoise_loss(cld_handle h, const float* z0, const float* noise, const float* cond, const int32_t* t_idx, float* z_noisy,
+                     float* mse, int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(h, "cld_denoise_loss", B, 0, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!z0 || !noise || !cond || !t_idx || !mse) return fail(h, CLD_ERR_ARG, "cld_denoise_loss: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(B);
+    Ws w = carve(workspace, bp);
+    // z_t = sqrt(acp[t]) z0 + sqrt(1 - acp[t]) noise  (q_sample, dm_model.py:91-96) straight into the padded latent buffer
+    HIPCK(h, launch_q_sample(z0, noise, t_idx, h->qs_tab, h->cfg.n_timesteps, w.xw, z_noisy, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    HIPCK(h, launch_add_time_bias(w.cb, h->tb, t_idx, h->cfg.n_timesteps, B, NCB, s));
+    HIPCK(h, run_unet(h, w, w.xw, -1, bp, s));
+    HeadArgs a{};
+    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = w.xtmp; a.B = B; a.b_pad = bp;
+    HIPCK(h, launch_head(a, s));
+    HIPCK(h, launch_mse_rows(noise, w.xtmp, mse, B, s));
     return CLD_OK;
 }
 

@@ -77,6 +77,13 @@ hipError_t launch_pack_latent(const float* x, float* xw, int B, int b_pad, hipSt
 // cb[b, n] = bias[n] + sum_k mish(cond[b,k]) * wc[n,k]   (b < B; pad rows = 0) ; wc is [ncb][256]
 hipError_t launch_cond_bias(const float* cond, const float* wc, const float* bias, float* cb,
                             int B, int b_pad, int ncb, hipStream_t s);
+// per-agent timesteps: cb[b, :] += tb[t_idx[b], :]  (time half of every block's Linear(Mish([t_emb | cond])), temporal.py:146)
+hipError_t launch_add_time_bias(float* cb, const float* tb, const int* t_idx, int n_timesteps, int B, int ncb, hipStream_t s);
+// q_sample (dm_model.py:91-96): xw[b] = qs[t_b] * z0[b] + qs[n + t_b] * noise[b] (pad rows zero); optional copy to z_noisy [B,52,4]
+hipError_t launch_q_sample(const float* z0, const float* noise, const int* t_idx, const float* qs, int n_timesteps, float* xw,
+                           float* z_noisy, int B, int b_pad, hipStream_t s);
+// out[b] = mean over (52 x 4) of (a - b)^2
+hipError_t launch_mse_rows(const float* a, const float* b, float* out, int B, hipStream_t s);
 // head: eps = W f + b (64 -> 4); mean = xc*x - nc*eps; x' = mean + sg*z
 struct HeadArgs {
     const float* f;      // [B_pad,52,64]

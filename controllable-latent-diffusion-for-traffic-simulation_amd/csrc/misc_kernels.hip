@@ -79,6 +79,61 @@ hipError_t launch_cond_bias(const float* cond, const float* wc, const float* bia
 }
 
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// per-agent timesteps (training-style calls: DmModel.compute_losses, dm_model.py:82-96, draws one t per sample)
+__global__ __launch_bounds__(256) void add_time_bias_kernel(float* __restrict__ cb, const float* __restrict__ tb,
+                                                           const int* __restrict__ t_idx, int n_timesteps, int ncb) {
+    const int b = blockIdx.x;
+    int t = t_idx[b];
+    t = t < 0 ? 0 : (t >= n_timesteps ? n_timesteps - 1 : t);
+    for (int i = threadIdx.x; i < ncb; i += 256) cb[(size_t)b * ncb + i] += tb[(size_t)t * ncb + i];
+}
+hipError_t launch_add_time_bias(float* cb, const float* tb, const int* t_idx, int n_timesteps, int B, int ncb, hipStream_t s) {
+    hipLaunchKernelGGL(add_time_bias_kernel, dim3(B), dim3(256), 0, s, cb, tb, t_idx, n_timesteps, ncb);
+    return hipGetLastError();
+}
+
+__global__ void q_sample_kernel(const float* __restrict__ z0, const float* __restrict__ noise, const int* __restrict__ t_idx,
+                                const float* __restrict__ qs, int n_timesteps, float* __restrict__ xw, float* __restrict__ zn,
+                                int nreal, int ntot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // one float4 = one (b, l) row
+    if (i >= ntot) return;
+    v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (i < nreal) {
+        int t = t_idx[i / 52];
+        t = t < 0 ? 0 : (t >= n_timesteps ? n_timesteps - 1 : t);
+        const float ca = qs[t], cn = qs[n_timesteps + t];
+        const v4f a = reinterpret_cast<const v4f*>(z0)[i], e = reinterpret_cast<const v4f*>(noise)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ca * a[k] + cn * e[k];
+        if (zn) reinterpret_cast<v4f*>(zn)[i] = v;
+    }
+    reinterpret_cast<v4f*>(xw)[i] = v;
+}
+hipError_t launch_q_sample(const float* z0, const float* noise, const int* t_idx, const float* qs, int n_timesteps, float* xw,
+                           float* z_noisy, int B, int b_pad, hipStream_t s) {
+    const int ntot = b_pad * 52, nreal = B * 52;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((ntot + 255) / 256), dim3(256), 0, s, z0, noise, t_idx, qs, n_timesteps, xw, z_noisy,
+                       nreal, ntot);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void mse_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int i = lane; i < 208; i += 64) {
+        const float d = a[(size_t)r * 208 + i] - b[(size_t)r * 208 + i];
+        s += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[r] = s * (1.0f / 208.0f);
+}
+hipError_t launch_mse_rows(const float* a, const float* b, float* out, int B, hipStream_t s) {
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(B), dim3(64), 0, s, a, b, out);
+    return hipGetLastError();
+}
+
 // head: eps = W f + b (final_conv.1, temporal.py:119) ; mean = xc*x - nc*eps ; x' = mean + sg*z
 // one thread per (b, l) row: reads 64 channels (256 B), writes 4 values.
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {

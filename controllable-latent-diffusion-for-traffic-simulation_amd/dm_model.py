@@ -62,11 +62,8 @@ class _UnetSurface:
         vals = torch.unique(time)
         if vals.numel() == 1:
             eps = self.engine.unet_forward(x, cond, int(vals[0]))
-        else:                                      # per-row timesteps: one launch group per distinct value
-            eps = torch.empty(x.shape, dtype=torch.float32, device=self.engine.device)
-            for v in vals.tolist():
-                idx = (time == v).nonzero().reshape(-1).to(self.engine.device)
-                eps[idx] = self.engine.unet_forward(x.to(self.engine.device)[idx], cond.to(self.engine.device)[idx], int(v))
+        else:                                      # per-row timesteps: the time bias is folded per agent (cld_unet_forward_t)
+            eps = self.engine.unet_forward_rows(x, cond, time)
         return eps.reshape(BN, M, T, -1) if four_d else eps
 
 
@@ -181,6 +178,20 @@ class DmModel:
         mean = float(self.engine.x_t_cof[i]) * xt - float(self.engine.noise_cof[i]) * noise
         logvar = torch.full((xt.shape[0], 1, 1), float(self.engine.posterior_log_variance_clipped[i]), device=xt.device)
         return mean, logvar
+
+    # ---- dm_model.py:82-96 (forward only: the validation loss of dm_trainer.py:84-90) ---------
+    def q_sample(self, x_0, t, noise):
+        return self.engine.denoise_loss(x_0, noise, torch.zeros(x_0.shape[0], 256, device=self.device), t, want_z_noisy=True)[1]
+
+    def compute_losses(self, aux_info, z0, t=None, noise=None):
+        """MSE between the drawn noise and the U-Net's prediction on q_sample(z0, t, noise); `t` / `noise` default to the
+        reference's draws (torch.randint / randn_like on the device).  No gradients: training is out of scope."""
+        B = len(z0)
+        if t is None:
+            t = torch.randint(0, self.n_timesteps, (B,), device=self.device)
+        if noise is None:
+            noise = torch.randn(B, 52, 4, device=self.device)
+        return self.engine.denoise_loss(z0, noise, aux_info["cond_feat"], t).mean()
 
     # ---- dm_model.py:165-174 -----------------------------------------------------------
     def log_prob(self, x_t, x_t_minus_1, aux_info, t):

@@ -138,6 +138,36 @@ class Engine:
                                                   self._stream()), "cld_unet_forward")
         return eps
 
+    def unet_forward_rows(self, x, cond, t):
+        """U-Net forward with one timestep per row: t [B] (any integer tensor)."""
+        x = self._f32(x)
+        B = x.shape[0]
+        x = self._f32(x, (B, T, D)); cond = self._f32(cond, (B, COND))
+        t = torch.as_tensor(t).reshape(-1).to(self.device, torch.int32).contiguous()
+        if t.numel() != B:
+            raise CldError(f"expected {B} timesteps, got {t.numel()}")
+        eps = torch.empty_like(x)
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_unet_forward_t(self._h, _ptr(x), _ptr(cond), _ptr(t), _ptr(eps), B, ws, wsn, self._stream()),
+                        "cld_unet_forward_t")
+        return eps
+
+    def denoise_loss(self, z0, noise, cond, t, want_z_noisy=False):
+        """Forward half of DmModel.compute_losses (dm_model.py:82-96): per-sample MSE [B] between `noise` and the U-Net's
+        prediction on q_sample(z0, t, noise); the reference's scalar loss is its mean."""
+        z0 = self._f32(z0)
+        B = z0.shape[0]
+        z0 = self._f32(z0, (B, T, D)); noise = self._f32(noise, (B, T, D)); cond = self._f32(cond, (B, COND))
+        t = torch.as_tensor(t).reshape(-1).to(self.device, torch.int32).contiguous()
+        mse = torch.empty(B, dtype=torch.float32, device=self.device)
+        zn = torch.empty_like(z0) if want_z_noisy else None
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_denoise_loss(self._h, _ptr(z0), _ptr(noise), _ptr(cond), _ptr(t), _ptr(zn), _ptr(mse), B,
+                                                  ws, wsn, self._stream()), "cld_denoise_loss")
+        return (mse, zn) if want_z_noisy else mse
+
     def ddpm_step(self, x, cond, t_idx: int, z):
         x = self._f32(x)
         B = x.shape[0]

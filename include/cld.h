@@ -109,6 +109,18 @@ int cld_get_schedule(cld_handle h, float* x_t_cof, float* noise_cof, float* post
 int cld_unet_forward(cld_handle h, const float* x, const float* cond, int32_t t_idx, float* eps,
                      int32_t B, void* workspace, size_t workspace_bytes, void* stream);
 
+/* cld_unet_forward with one timestep PER ROW (t_idx [B] DEVICE int32): TemporalMapUnet.forward accepts any `time [B]`
+ * (temporal.py:122-146); training-style callers draw a different t per sample (dm_model.py:84). */
+int cld_unet_forward_t(cld_handle h, const float* x, const float* cond, const int32_t* t_idx, float* eps, int32_t B,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* The forward half of DmModel.compute_losses (dm_model.py:82-96; src/trainers/dm_trainer.py:84-90 validation_step):
+ * z_t = q_sample(z0, t, noise) = sqrt(acp[t]) z0 + sqrt(1 - acp[t]) noise, eps = U-Net(z_t, cond, t) and
+ * mse[b] = mean_{T,D} (noise - eps)^2, so that F.mse_loss(noise, eps) = mean_b mse[b].  z0, noise [B,52,4]; t_idx [B]
+ * DEVICE int32; z_noisy [B,52,4] optional (NULL to skip).  Forward only: training itself is out of scope. */
+int cld_denoise_loss(cld_handle h, const float* z0, const float* noise, const float* cond, const int32_t* t_idx, float* z_noisy,
+                     float* mse, int32_t B, void* workspace, size_t workspace_bytes, void* stream);
+
 /* (x_{t-1}, mean, sigma) = DmModel.x_Tminus1(x, t, aux_info)  (dm_model.py:144-163).
  * z [B,52,4] is the caller's N(0,1) draw (the reference's randn_like, :153).
  * x_next / mean [B,52,4] (either may be NULL); *sigma_host receives exp(0.5*logvar[t]). */

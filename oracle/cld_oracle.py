@@ -205,6 +205,16 @@ def sample_cfg(w, sched, x_T: Tensor, noise: Tensor, cond: Tensor, non_cond: Ten
     return {"pred_traj": x, "x1": x1}
 
 
+def q_sample(sched, x0: Tensor, t: Tensor, noise: Tensor) -> Tensor:
+    """dm_model.py:91-96 -- sqrt(acp[t]) x0 + sqrt(1 - acp[t]) noise, per-row t."""
+    return sched["sqrt_alphas_cumprod"][t].view(-1, 1, 1) * x0 + sched["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1) * noise
+
+
+def compute_losses(w, sched, z0: Tensor, cond: Tensor, t: Tensor, noise: Tensor) -> Tensor:
+    """dm_model.py:82-89 with the draws (t, noise) supplied: F.mse_loss(noise, U-Net(q_sample(z0, t, noise), cond, t))."""
+    return F.mse_loss(noise, unet_forward(w, q_sample(sched, z0, t, noise), cond, t))
+
+
 def log_prob(w, sched, x_t: Tensor, x_tm1: Tensor, cond: Tensor, i: int) -> Tensor:
     """dm_model.py:165-174 -- log N(x_{t-1}; mean(x_t, eps), sigma_t) averaged over (T, D)."""
     B = x_t.shape[0]

@@ -279,6 +279,28 @@ def section_stride(ref):
          pred_traj=out["pred_traj"], log_prob_final=out["log_prob_final"])
 
 
+def section_losses(ref):
+    """DmModel.compute_losses / q_sample (dm_model.py:82-96; the validation loss of dm_trainer.py:84-90) with the reference's
+    two draws supplied: t through a patched torch.randint, noise through randn_like."""
+    n, B = 100, 16
+    dm = build_dm(ref, n, True)
+    inp = synth.make_inputs(B, IN_SEED)
+    z0 = T(synth.normal(IN_SEED, "loss_z0", (B, 52, 4)))
+    noise = T(synth.normal(NOISE_SEED, "loss_noise", (B, 52, 4)))
+    t = torch.from_numpy((synth.uniform(IN_SEED, "loss_t", (B,), 0.0, 1.0) * n).astype(np.int64)).clamp(0, n - 1)
+    o_randint = torch.randint
+    torch.randint = lambda *a, **k: t.clone()
+    try:
+        with torch.no_grad(), feed_noise([noise]):
+            loss = dm.compute_losses({"cond_feat": T(inp["cond_feat"])}, z0)
+            zn = dm.q_sample(z0, t, noise)
+    finally:
+        torch.randint = o_randint
+    save("compute_losses", {"B": B, "n_timesteps": n, "w_seed": W_SEED, "affine_jitter": True, "in_seed": IN_SEED, "noise_seed": NOISE_SEED,
+                            "z0": "normal(in_seed,'loss_z0')", "noise": "normal(noise_seed,'loss_noise')", "t": "uniform(in_seed,'loss_t')*n"},
+         t=t, z_noisy=zn, loss=loss.reshape(1))
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -286,7 +308,7 @@ def main():
     algo = ref.algo
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
-            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride}[name](ref)
+            {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride, "losses": section_losses}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
@@ -294,6 +316,7 @@ def main():
     section_guidance(ref)
     section_reward(ref)
     section_stride(ref)
+    section_losses(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

@@ -710,3 +710,25 @@ def test_sample_with_stride_golden(golden):
     assert np.abs(out["log_prob_final"].cpu().numpy() - g["log_prob_final"]).max() <= 1e-4
     with pytest.raises(CldError):
         dm.engine.sample(torch.from_numpy(nz["x_T"]), cond, noise=torch.zeros(100, B, 52, 4))
+
+
+def test_compute_losses_golden(golden, eng_jitter):
+    """DmModel.compute_losses / q_sample / per-row timesteps of `dm.model` against the reference (golden 'compute_losses')."""
+    from cld_amd.dm_model import DmModel
+    from oracle import cld_oracle as O
+    meta, g = golden("compute_losses")
+    B = meta["B"]
+    dm = DmModel(None, None, n_timesteps=100, engine=eng_jitter)
+    z0 = torch.from_numpy(synth.normal(meta["in_seed"], "loss_z0", (B, 52, 4))).cuda()
+    noise = torch.from_numpy(synth.normal(meta["noise_seed"], "loss_noise", (B, 52, 4))).cuda()
+    t = torch.from_numpy(g["t"]).cuda()
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"]).cuda()
+    assert np.abs(dm.q_sample(z0, t, noise).cpu().numpy() - g["z_noisy"]).max() <= 1e-6
+    loss = float(dm.compute_losses({"cond_feat": cond}, z0, t=t, noise=noise))
+    assert abs(loss - float(g["loss"][0])) <= 1e-4 * max(1.0, float(g["loss"][0]))
+    # per-row timesteps through dm.model equal the single-timestep path row by row
+    eps = dm.model(torch.from_numpy(g["z_noisy"]).cuda(), {"cond_feat": cond}, t)
+    for b in (0, 5, 15):
+        one = eng_jitter.unet_forward(torch.from_numpy(g["z_noisy"][b:b + 1]).cuda(), cond[b:b + 1], int(t[b]))
+        assert (eps[b] - one[0]).abs().max().item() <= 2e-5 * max(1.0, one.abs().max().item())
+    assert float(dm.compute_losses({"cond_feat": cond}, z0)) > 0.0          # own draws

@@ -282,3 +282,16 @@ def test_sample_with_stride_vs_reference(golden):
     assert out["x1"] is None
     assert np.abs(out["pred_traj"].numpy() - g["pred_traj"]).max() <= 1e-5 * max(1.0, scale)
     assert np.abs(out["log_prob_final"].numpy() - g["log_prob_final"]).max() <= 1e-4
+
+
+def test_compute_losses_vs_reference(golden):
+    """DmModel.compute_losses / q_sample (dm_model.py:82-96) with per-sample timesteps, recorded from the reference."""
+    meta, g = golden("compute_losses")
+    B, n = meta["B"], meta["n_timesteps"]
+    w, s = W(meta["affine_jitter"]), O.schedule(n)
+    z0 = torch.from_numpy(synth.normal(meta["in_seed"], "loss_z0", (B, 52, 4)))
+    noise = torch.from_numpy(synth.normal(meta["noise_seed"], "loss_noise", (B, 52, 4)))
+    t = torch.from_numpy(g["t"])
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    assert np.abs(O.q_sample(s, z0, t, noise).numpy() - g["z_noisy"]).max() <= 1e-6
+    assert abs(float(O.compute_losses(w, s, z0, cond, t, noise)) - float(g["loss"][0])) <= 1e-5 * max(1.0, float(g["loss"][0]))
