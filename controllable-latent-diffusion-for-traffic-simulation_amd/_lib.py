@@ -67,6 +67,7 @@ SIGNATURES = {
     "cld_action_to_state": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "cld_decode": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "cld_traj2z": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "cld_vae_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_state_to_state_and_action": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "cld_context_workspace_bytes": (C.c_size_t, [_P, C.c_int32]),
     "cld_context_encode": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P]),

@@ -1124,6 +1124,16 @@ int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const fl
     return CLD_OK;
 }
 
+int cld_vae_loss(cld_handle h, const float* x6_scaled, const float* act_out, const float* mu, const float* logvar, float beta,
+                 float* out3, int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!x6_scaled || !act_out || !mu || !logvar || !out3 || B < 1) return fail(h, CLD_ERR_ARG, "cld_vae_loss: bad argument");
+    if (!workspace || workspace_bytes < (size_t)B * 2 * sizeof(float)) return fail(h, CLD_ERR_WORKSPACE, "cld_vae_loss: workspace too small");
+    HIPCK(h, launch_vae_loss(x6_scaled, act_out, mu, logvar, beta, static_cast<float*>(workspace), out3, B,
+                             static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
 int cld_state_to_state_and_action(cld_handle h, const float* positions, const float* yaws, const float* curr_speed,
                                   float* out6, int32_t B, int32_t scaled_output, void* stream) {
     if (!h) return CLD_ERR_ARG;

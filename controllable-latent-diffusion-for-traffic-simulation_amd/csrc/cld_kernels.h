@@ -82,6 +82,10 @@ hipError_t launch_add_time_bias(float* cb, const float* tb, const int* t_idx, in
 // q_sample (dm_model.py:91-96): xw[b] = qs[t_b] * z0[b] + qs[n + t_b] * noise[b] (pad rows zero); optional copy to z_noisy [B,52,4]
 hipError_t launch_q_sample(const float* z0, const float* noise, const int* t_idx, const float* qs, int n_timesteps, float* xw,
                            float* z_noisy, int B, int b_pad, hipStream_t s);
+// VaeModel.compute_vae_loss forward: x6 [B,52,6] scaled input, act [B,52,2], mu / lv [B,52,4] -> out = (loss, recon, kld);
+// part: 2 B floats of scratch
+hipError_t launch_vae_loss(const float* x6, const float* act, const float* mu, const float* lv, float beta, float* part, float* out,
+                           int B, hipStream_t s);
 // out[b] = mean over (52 x 4) of (a - b)^2
 hipError_t launch_mse_rows(const float* a, const float* b, float* out, int B, hipStream_t s);
 // head: eps = W f + b (64 -> 4); mean = xc*x - nc*eps; x' = mean + sg*z

@@ -134,6 +134,50 @@ hipError_t launch_mse_rows(const float* a, const float* b, float* out, int B, hi
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// VaeModel.compute_vae_loss (models/vae/vae_model.py:89-99), forward only:
+//   recon = mse(input[..., 4:6], output) ; kld = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) / (B * T) ; loss = recon + beta * kld
+// stage 1: one wave per agent -> part[b] = (sum of squared action errors, sum of the KLD integrand)
+__global__ __launch_bounds__(64) void vae_loss_part_kernel(const float* __restrict__ x6, const float* __restrict__ act,
+                                                          const float* __restrict__ mu, const float* __restrict__ lv,
+                                                          float* __restrict__ part) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float se = 0.f, kl = 0.f;
+    for (int i = lane; i < 104; i += 64) {
+        const float d = x6[(size_t)b * 312 + (i >> 1) * 6 + 4 + (i & 1)] - act[(size_t)b * 104 + i];
+        se += d * d;
+    }
+    for (int i = lane; i < 208; i += 64) {
+        const float m = mu[(size_t)b * 208 + i], l = lv[(size_t)b * 208 + i];
+        kl += 1.0f + l - m * m - expf(l);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o); kl += __shfl_xor(kl, o); }
+    if (lane == 0) { part[2 * b] = se; part[2 * b + 1] = kl; }
+}
+// stage 2: one workgroup sums the agents in a fixed order (deterministic) -> out = (loss, recon, kld)
+__global__ __launch_bounds__(256) void vae_loss_final_kernel(const float* __restrict__ part, int B, float beta, float* __restrict__ out) {
+    __shared__ float s0[256], s1[256];
+    float a = 0.f, c = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { a += part[2 * b]; c += part[2 * b + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float recon = s0[0] / ((float)B * 104.0f), kld = -0.5f * s1[0] / ((float)B * 52.0f);
+        out[0] = recon + beta * kld; out[1] = recon; out[2] = kld;
+    }
+}
+hipError_t launch_vae_loss(const float* x6, const float* act, const float* mu, const float* lv, float beta, float* part, float* out,
+                           int B, hipStream_t s) {
+    hipLaunchKernelGGL(vae_loss_part_kernel, dim3(B), dim3(64), 0, s, x6, act, mu, lv, part);
+    hipLaunchKernelGGL(vae_loss_final_kernel, dim3(1), dim3(256), 0, s, part, B, beta, out);
+    return hipGetLastError();
+}
+
 // head: eps = W f + b (final_conv.1, temporal.py:119) ; mean = xc*x - nc*eps ; x' = mean + sg*z
 // one thread per (b, l) row: reads 64 channels (256 B), writes 4 values.
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {

@@ -367,6 +367,18 @@ class Engine:
                                             self._stream()), "cld_traj2z")
         return z, mu, lv
 
+    def vae_loss(self, x6_scaled, act_out, mu, logvar, beta: float):
+        """VaeModel.compute_vae_loss (vae_model.py:89-99), forward only -> tensor [3] = (loss, recon, kld)."""
+        x = self._f32(x6_scaled)
+        B = x.shape[0]
+        x = self._f32(x, (B, T, 6)); a = self._f32(act_out, (B, T, 2)); m = self._f32(mu, (B, T, D)); l = self._f32(logvar, (B, T, D))
+        out = torch.empty(3, dtype=torch.float32, device=self.device)
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_vae_loss(self._h, _ptr(x), _ptr(a), _ptr(m), _ptr(l), C.c_float(beta), _ptr(out), B, ws, wsn,
+                                              self._stream()), "cld_vae_loss")
+        return out
+
     def state_to_state_and_action(self, positions, yaws, curr_speed, scaled_output=False):
         p = self._f32(positions)
         B = p.shape[0]

@@ -62,14 +62,20 @@ class VaeModel:
         return aux_info, self.get_state_and_action_from_data_batch(batch, scaled=True), sa
 
     def forward(self, batch, beta=None, noise=None):
-        """VaeModel.forward (vae_model.py:64-82) without the loss terms (training is out of scope): the reconstruction
-        path pre_vae -> lstmvae -> convert_action_to_state_and_action -> descale, same dict keys for what is returned."""
+        """VaeModel.forward (vae_model.py:64-82), forward values only (training is out of scope): pre_vae -> lstmvae ->
+        convert_action_to_state_and_action -> descale, and the loss terms of compute_vae_loss; the reference's dict keys."""
         aux_info, sa_scaled, _ = self.pre_vae(batch)
         recon_act, mu, logvar = self.lstmvae(sa_scaled, aux_info["cond_feat"], noise)
         recon = self.convert_action_to_state_and_action(recon_act, aux_info["curr_states"], descaled_output=True)
-        return {"hist": batch["history_positions"], "input": batch.get("target_positions"), "output": recon[..., :2],
+        lt = self.engine.vae_loss(sa_scaled, recon_act, mu, logvar, 0.0 if beta is None else float(beta))
+        return {"loss": lt[0], "recon": lt[1], "kld": lt[2], "hist": batch["history_positions"], "input": batch.get("target_positions"), "output": recon[..., :2],
                 "raster_from_agent": batch.get("raster_from_agent"), "image": batch["image"], "mu": mu, "logvar": logvar,
                 "recon_act": recon_act}
+
+    def compute_vae_loss(self, input, output, mu, logvar, beta):
+        """vae_model.py:89-99 -> (loss, recon, kld), forward only."""
+        lt = self.engine.vae_loss(input, output, mu, logvar, float(beta))
+        return lt[0], lt[1], lt[2]
 
     def convert_action_to_state_and_action(self, x_out, curr_states, scaled_input=True, descaled_output=False):
         four_d = x_out.dim() == 4          # vae_model.py:108-111

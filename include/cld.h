@@ -241,6 +241,12 @@ int cld_decode(cld_handle h, const float* z, const float* cond, const float* cur
 int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const float* noise, float* z, float* mu,
                float* logvar, int32_t B, void* stream);
 
+/* VaeModel.compute_vae_loss (models/vae/vae_model.py:89-99), forward only: recon = mse(x6_scaled[..., 4:6], act_out),
+ * kld = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) / (B * 52), loss = recon + beta * kld.  out3 = (loss, recon, kld), DEVICE;
+ * workspace >= 2 * B floats (cld_workspace_bytes(h, B) is more than enough). */
+int cld_vae_loss(cld_handle h, const float* x6_scaled, const float* act_out, const float* mu, const float* logvar, float beta,
+                 float* out3, int32_t B, void* workspace, size_t workspace_bytes, void* stream);
+
 /* convert_state_to_state_and_action(traj_state, vel_init, dt)  (src/tbsim/models/diffuser_helpers.py:685-749) as
  * called by get_state_and_action_from_data_batch (models/context_utils.py:64-70): positions [B,52,2], yaws [B,52,1],
  * curr_speed [B] -> [B,52,6]; scaled_output != 0 also applies VaeModel.scale_traj (vae_model.py:131-155). */

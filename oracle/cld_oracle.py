@@ -521,5 +521,13 @@ def compute_reward(traj: Tensor, traj_scaled: Tensor, raster_from_agent: Tensor,
     return off + col - jerk * 0.1, off, col
 
 
+def vae_loss(x6_scaled: Tensor, act_out: Tensor, mu: Tensor, logvar: Tensor, beta: float):
+    """models/vae/vae_model.py:89-99 -> (loss, recon, kld)."""
+    recon = F.mse_loss(x6_scaled[..., -2:], act_out, reduction="mean")
+    B, T, _ = mu.shape
+    kld = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) / (B * T)
+    return recon + beta * kld, recon, kld
+
+
 def to_torch(d: dict, dtype=torch.float32) -> Dict[str, Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in d.items()}

@@ -133,6 +133,10 @@ def section_encoder(ref):
     nz = T(synth.normal(NOISE_SEED, "enc_noise", (B, 52, 4)))
     with torch.no_grad(), feed_noise([nz]):
         z, mu, lv = vae.traj2z(x6s, cond)
+    act_out = vae.lstm_dec(z, cond).detach()
+    loss, recon, kld = ref.VaeModel.compute_vae_loss(None, x6s, act_out, mu, lv, 0.5)      # vae_model.py:89-99 (self is unused)
+    save("vae_loss", {"B": B, "beta": 0.5, "inputs": "as fixture 'encode': x6 scaled, lstm_dec(z), mu, logvar"},
+         loss=torch.stack([loss, recon, kld]).detach())
     save("encode", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "noise_seed": NOISE_SEED,
                     "future": "synth.make_future(B, in_seed)", "noise": "normal(noise_seed,'enc_noise')"},
          state_action=x6, z=z, mu=mu, logvar=lv)

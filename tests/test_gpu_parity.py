@@ -732,3 +732,24 @@ def test_compute_losses_golden(golden, eng_jitter):
         one = eng_jitter.unet_forward(torch.from_numpy(g["z_noisy"][b:b + 1]).cuda(), cond[b:b + 1], int(t[b]))
         assert (eps[b] - one[0]).abs().max().item() <= 2e-5 * max(1.0, one.abs().max().item())
     assert float(dm.compute_losses({"cond_feat": cond}, z0)) > 0.0          # own draws
+
+
+def test_vae_loss_golden(golden):
+    """VaeModel.compute_vae_loss forward (recon MSE + beta * KLD) against the reference (golden 'vae_loss')."""
+    from cld_amd.engine import Engine
+    from cld_amd.vae_model import VaeModel
+    meta, g = golden("vae_loss")
+    _, ge = golden("encode")
+    B = meta["B"]
+    e = Engine(n_timesteps=10, device="cuda:0")
+    for sd in (synth.make_unet_weights(0), synth.make_decoder_weights(0), synth.make_encoder_weights(0)):
+        e.load_state_dict(sd)
+    e.finalize()
+    vae = VaeModel(engine=e)
+    cond = torch.from_numpy(synth.make_inputs(B, 1)["cond_feat"]).cuda()
+    fut = synth.make_future(B, 1)
+    x6s = e.state_to_state_and_action(fut["target_positions"], fut["target_yaws"], fut["curr_speed"], scaled_output=True)
+    act = vae.lstmvae.lstm_dec(torch.from_numpy(ge["z"]), cond)
+    loss, recon, kld = vae.compute_vae_loss(x6s, act, torch.from_numpy(ge["mu"]), torch.from_numpy(ge["logvar"]), meta["beta"])
+    got = np.array([float(loss), float(recon), float(kld)])
+    assert np.abs(got - g["loss"]).max() <= 1e-4 * max(1.0, np.abs(g["loss"]).max())

@@ -295,3 +295,18 @@ def test_compute_losses_vs_reference(golden):
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
     assert np.abs(O.q_sample(s, z0, t, noise).numpy() - g["z_noisy"]).max() <= 1e-6
     assert abs(float(O.compute_losses(w, s, z0, cond, t, noise)) - float(g["loss"][0])) <= 1e-5 * max(1.0, float(g["loss"][0]))
+
+
+def test_vae_loss_vs_reference(golden):
+    """VaeModel.compute_vae_loss (vae_model.py:89-99) on the encoder fixture's tensors, recorded from the reference."""
+    meta, g = golden("vae_loss")
+    _, ge = golden("encode")
+    B = meta["B"]
+    wd = O.to_torch(synth.make_decoder_weights(0))
+    cond = torch.from_numpy(synth.make_inputs(B, 1)["cond_feat"])
+    fut = synth.make_future(B, 1)
+    x6s = O.state_to_state_and_action(torch.from_numpy(fut["target_positions"]), torch.from_numpy(fut["target_yaws"]),
+                                      torch.from_numpy(fut["curr_speed"]), scaled=True)
+    act = O.lstm_decode(wd, torch.from_numpy(ge["z"]), cond)
+    got = torch.stack(O.vae_loss(x6s, act, torch.from_numpy(ge["mu"]), torch.from_numpy(ge["logvar"]), meta["beta"]))
+    assert np.abs(got.numpy() - g["loss"]).max() <= 1e-5 * max(1.0, np.abs(g["loss"]).max())
