@@ -448,6 +448,17 @@ class Engine:
                         "cld_compute_reward")
         return r, o, c
 
+    def failure_rate_compute(self, state_action, batch: Mapping):
+        """models/rl/criticmodel.py:114-145: {'offroad_failure_rate', 'collision_failure_rate', 'overall_failure_rate'} from the
+        per-agent offroad / collision terms of `compute_reward` (an agent fails if it leaves the drivable area at any step,
+        respectively comes within 0.8 m of another agent); same batch keys as the reference."""
+        _, off, col = self.compute_reward(state_action, None, batch["raster_from_agent"], batch["drivable_map"],
+                                          batch.get("all_other_agents_future_positions"),
+                                          batch.get("all_other_agents_future_availability"))
+        o = float((off < 0).float().mean())
+        c = float((col < 0).float().mean())
+        return {"offroad_failure_rate": o, "collision_failure_rate": c, "overall_failure_rate": (o + c) / 2.0}
+
     def world_step(self, traj, centroid, yaw, k: int):
         """env_trajdata.py:452-468 for plan step k -> (world [B,3] = (x, y, h), next curr_states [B,4])."""
         traj = self._f32(traj)

@@ -344,6 +344,11 @@ def test_reward_golden_and_oracle(golden, eng_jitter):
                                   ri["other_avail"])
     assert torch.equal(off.cpu(), ro) and torch.equal(col.cpu(), rc)
     assert (r.cpu() - rr).abs().max().item() <= 1e-5 * max(1.0, rr.abs().max().item())
+    rates = eng_jitter.failure_rate_compute(ri["traj"], {"raster_from_agent": ri["raster_from_agent"], "drivable_map": ri["drivable_map"],
+                                                         "all_other_agents_future_positions": ri["other_pos"],
+                                                         "all_other_agents_future_availability": ri["other_avail"]})
+    for k, v in meta["rates"].items():                      # the reference's failure_rate_compute on the same batch
+        assert abs(rates[k] - v) <= 1e-6, k
     # no other agents: collision term vanishes
     r2, _, c2 = eng_jitter.compute_reward(ri["traj"], ri["traj_scaled"], ri["raster_from_agent"], ri["drivable_map"])
     assert float(c2.abs().max()) == 0.0
