@@ -565,12 +565,12 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
                     const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][n][16 * jj + 4 * rb]);
                     const v4f hb = *reinterpret_cast<const v4f*>(&hs[1][pr][n][16 * jj + 4 * rb]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e) {      // the four gate accumulators in turn: no back-to-back dependent MFMAs
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[g][jj][e], acc[g], 0, 0, 0);
-                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[g][jj][e], acc[g], 0, 0, 0);
-                        }
+                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[g][jj][e], acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[g][jj][e], acc[g], 0, 0, 0);
+                    }
                 }
                 kp += 5 * 4 * 256;
                 float ap[4], aq[4];
@@ -686,19 +686,24 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
                 __syncthreads();
                 if (t > 0) fetch(kv1, t - 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                v4f pc = {0.f, 0.f, 0.f, 0.f}, pz = {0.f, 0.f, 0.f, 0.f};
+                // three accumulators in turn (two halves of the recurrent product + the dL/dz product): a lone accumulator would
+                // make every MFMA wait for its predecessor
+                v4f pc = {0.f, 0.f, 0.f, 0.f}, pc2 = {0.f, 0.f, 0.f, 0.f}, pz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
+                for (int jj = 0; jj < 8; ++jj) {
                     const v4f ga = *reinterpret_cast<const v4f*>(&dG[1][n][16 * jj + 4 * rb]);
+                    const v4f gb = *reinterpret_cast<const v4f*>(&dG[1][n][16 * (jj + 8) + 4 * rb]);
+                    v4f gz = ga;
+                    if (jj < 4) gz = *reinterpret_cast<const v4f*>(&dG[1][n][64 * wv + 16 * jj + 4 * rb]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_hh0[jj][e], pc, 0, 0, 0);   // -> rec0 of step t-1
+                    for (int e = 0; e < 4; ++e) {
+                        pc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_hh0[jj][e], pc, 0, 0, 0);        // -> rec0 of step t-1
+                        pc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[e], t_hh0[jj + 8][e], pc2, 0, 0, 0);
+                        if (jj < 4) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(gz[e], t_ih0[jj][e], pz, 0, 0, 0);
+                    }
                 }
 #pragma unroll
-                for (int jq = 0; jq < 4; ++jq) {
-                    const v4f ga = *reinterpret_cast<const v4f*>(&dG[1][n][64 * wv + 16 * jq + 4 * rb]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_ih0[jq][e], pz, 0, 0, 0);
-                }
+                for (int r = 0; r < 4; ++r) pc[r] += pc2[r];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rec0[r] = pc[r];
                 if (n < 4) {
