@@ -203,3 +203,11 @@ def test_guidance_config_adapter_matches_the_golden_configurations():
         guidance_from_config([[{"name": "agent_collision", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
     with pytest.raises(ValueError):
         guidance_from_config([[]], scene_index)
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md's table maps every symbol include/cld.h declares to the reference interface it replaces."""
+    hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [s for s in set(re.findall(r"\b(cld_[a-z_0-9]+)\s*\(", hdr)) if s not in doc]
+    assert not missing, missing
