@@ -180,7 +180,8 @@ def main():
                     "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                    else "v_mfma_f32_16x16x4_f32 dense peak"),
                     "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0> (Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; "
-                               "7 launches per U-Net evaluation, every 10th evaluation timed; tiling picked by batch size)"
+                               "8 launches per U-Net evaluation -- 7 with 256 input channels, 1 with 128 -- every 10th evaluation timed; "
+                               "tiling picked by batch size)"
                                % ("4,1" if (B + 15) // 16 * 4 * 4 >= 2048 else ("4,2" if B >= 1024 else "2,2"))),
                     "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
                     "flop_per_launch": flop / launches}
