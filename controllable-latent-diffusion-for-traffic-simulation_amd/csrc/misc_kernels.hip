@@ -3,6 +3,8 @@
 //   with the DDPM update, reference models/dm/dm_model.py:144-163), log-prob
 //   (dm_model.py:130-132,165-174), the LSTM-VAE decoder (models/vae/lstm_vae.py:28-52)
 //   and the unicycle roll-out (src/tbsim/models/diffuser_helpers.py:541-639, 'parallel').
+#include <cstdlib>
+
 #include "cld_kernels.h"
 
 namespace cld {
@@ -396,8 +398,153 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecoderWeights w, con
         (void)u;
     }
 }
+// MFMA formulation of the decoder for batches that fill it: 16 agents per workgroup, the gate pre-activations of a layer
+// step as the GEMM [16 agents x K] x [K x 256] on v_mfma_f32_16x16x4_f32.  Wave w owns hidden units 16w..16w+15 and the
+// four N-tiles {i, f, g, o} of those units, so the MFMA result layout (lane = (unit n, agent block rb), 4 registers = agents
+// 4rb..4rb+3) holds all four gates of one (agent, unit) cell in one lane: the cell update runs in registers, only h passes
+// through LDS as the next product's A operand (float4 reads: 4 consecutive k per lane, element e feeds MFMA e; the register-
+// resident B fragments use the same k permutation) -- two barriers per time step, 196 MFMAs per wave per step.
+// v_exp_f32 / v_rcp_f32 forms (1 ulp each): ~1e-7 absolute on the gates, far inside the decode bars; the libm forms cost as
+// many cycles per step here as the 196 MFMAs do
+__device__ __forceinline__ float fsig_m(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh_m(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+__global__ __launch_bounds__(256) void decode_mfma_kernel(const DecoderWeights w, const DynParams d,
+                                                          const float* __restrict__ z, const float* __restrict__ cond,
+                                                          const float* __restrict__ cs, float* __restrict__ act_out,
+                                                          float* __restrict__ traj, int B, int descaled_output) {
+    constexpr int AG = 16, HS = 68;
+    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
+    __shared__ __attribute__((aligned(16))) float zin[AG][208];
+    __shared__ __attribute__((aligned(16))) float condm[AG][256];
+    __shared__ float actp[2][52][4][AG];     // per-wave partials of hid2act
+    __shared__ float act[AG][104];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, rb = lane >> 4;
+    const int u = 16 * wv + n;
+    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u];
+    // B fragments: gate g, k-step (jj, e) -> W[col = 64 g + 16 wv + n][k = 16 jj + 4 rb + e]
+    float f_hh0[4][4][4], f_ih1[4][4][4], f_hh1[4][4][4], f_ih0[4], fb0[4], fb1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = 64 * g + 16 * wv + n;
+        f_ih0[g] = w.w_ih0[col * 4 + rb];
+        fb0[g] = w.b0[col];
+        fb1[g] = w.b1[col];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const v4f x0 = *reinterpret_cast<const v4f*>(w.w_hh0 + col * 64 + 16 * jj + 4 * rb);
+            const v4f x1 = *reinterpret_cast<const v4f*>(w.w_ih1 + col * 64 + 16 * jj + 4 * rb);
+            const v4f x2 = *reinterpret_cast<const v4f*>(w.w_hh1 + col * 64 + 16 * jj + 4 * rb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f_hh0[g][jj][e] = x0[e]; f_ih1[g][jj][e] = x1[e]; f_hh1[g][jj][e] = x2[e]; }
+        }
+    }
+    const int ngroups = (B + AG - 1) / AG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * AG;
+        auto agent = [&](int ag) { return (b0 + ag < B) ? b0 + ag : B - 1; };      // tail slots replay the last agent; never stored
+        for (int i = tid; i < AG * 256; i += 256) condm[i >> 8][i & 255] = cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
+        for (int i = tid; i < AG * 208; i += 256) zin[i / 208][i % 208] = z[(size_t)agent(i / 208) * 208 + i % 208];
+        __syncthreads();
+        for (int i = tid; i < AG * 64; i += 256) {      // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49)
+            const int ag = i >> 6, uu = i & 63;
+            float s = w.b_c2h[uu];
+            const float* wr = w.w_c2h + uu * 256;
+            for (int k = 0; k < 256; ++k) s = fmaf(condm[ag][k], wr[k], s);
+            hs[0][0][ag][uu] = s;
+            hs[1][0][ag][uu] = s;
+        }
+        float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int t = 0; t < 52; ++t) {
+            const int pr = t & 1;
+            v4f acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = v4f{fb0[g], fb0[g], fb0[g], fb0[g]};
+            {
+                const float xa = zin[n][4 * t + rb];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f_ih0[g], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_hh0[g][jj][e], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = fsig_m(acc[0][r]), fg = fsig_m(acc[1][r]), gg = ftanh_m(acc[2][r]), og = fsig_m(acc[3][r]);
+                const float c = fg * c0[r] + ig * gg;
+                c0[r] = c;
+                hs[0][pr ^ 1][4 * rb + r][u] = og * ftanh_m(c);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = v4f{fb1[g], fb1[g], fb1[g], fb1[g]};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][n][16 * jj + 4 * rb]);
+                const v4f hb = *reinterpret_cast<const v4f*>(&hs[1][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[g][jj][e], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[g][jj][e], acc[g], 0, 0, 0);
+                }
+            }
+            float ap[4], aq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = fsig_m(acc[0][r]), fg = fsig_m(acc[1][r]), gg = ftanh_m(acc[2][r]), og = fsig_m(acc[3][r]);
+                const float c = fg * c1[r] + ig * gg;
+                c1[r] = c;
+                const float hn = og * ftanh_m(c);
+                hs[1][pr ^ 1][4 * rb + r][u] = hn;
+                ap[r] = hn * wa0;
+                aq[r] = hn * wa1;
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ap[r] += __shfl_xor(ap[r], o); aq[r] += __shfl_xor(aq[r], o); }
+            if (n == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { actp[0][t][wv][4 * rb + r] = ap[r]; actp[1][t][wv][4 * rb + r] = aq[r]; }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < AG * 104; i += 256) {      // hid2act: sum the four waves' partials in wave order + bias
+            const int ag = i / 104, k = i % 104, t = k >> 1, c = k & 1;
+            act[ag][k] = actp[c][t][0][ag] + actp[c][t][1][ag] + actp[c][t][2][ag] + actp[c][t][3][ag] + w.b_h2a[c];
+        }
+        __syncthreads();
+        if (act_out)
+            for (int i = tid; i < AG * 104; i += 256)
+                if (b0 + i / 104 < B) act_out[(size_t)(b0 + i / 104) * 104 + i % 104] = act[i / 104][i % 104];
+        if (traj && tid < AG && b0 + tid < B)
+            rollout_agent(d, &act[tid][0], cs + (size_t)(b0 + tid) * 4, traj + (size_t)(b0 + tid) * 312, true, descaled_output != 0);
+        __syncthreads();
+    }
+}
+
 hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond, const float* cs,
                          float* act, float* traj, int B, int descaled_output, hipStream_t s) {
+    // from 256 agents (16 workgroups of 16) the MFMA kernel is faster than one VALU workgroup per agent
+    // (CLD_DECODE_KERNEL=valu|mfma overrides, experiments only)
+    const char* force = getenv("CLD_DECODE_KERNEL");
+    const bool mfma = force ? force[0] == 'm' : B >= 256;
+    if (mfma) {
+        const int groups = (B + 15) / 16;
+        hipLaunchKernelGGL(decode_mfma_kernel, dim3(groups < 1024 ? groups : 1024), dim3(256), 0, s, w, d, z, cond, cs, act,
+                           cs ? traj : nullptr, B, descaled_output);
+        return hipGetLastError();
+    }
     const int grid = B < 2048 ? B : 2048;
     hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, s, w, d, z, cond, cs, act, cs ? traj : nullptr, B,
                        descaled_output);

@@ -758,3 +758,31 @@ def test_vae_loss_golden(golden):
     loss, recon, kld = vae.compute_vae_loss(x6s, act, torch.from_numpy(ge["mu"]), torch.from_numpy(ge["logvar"]), meta["beta"])
     got = np.array([float(loss), float(recon), float(kld)])
     assert np.abs(got - g["loss"]).max() <= 1e-4 * max(1.0, np.abs(g["loss"]).max())
+
+
+def test_decode_mfma_kernel_vs_oracle_and_valu(eng_jitter):
+    """The 16-agents-per-workgroup MFMA formulation of the decoder (taken from 256 agents up): against the oracle at B = 300
+    (ragged last tile) with the decode bars (actions 2e-5, trajectories 1e-4), and against the one-agent-per-workgroup kernel."""
+    import os
+    from oracle import cld_oracle as O
+    B = 300
+    inp = synth.make_inputs(B, 51)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    z = torch.from_numpy(synth.normal(51, "z", (B, 52, 4)))
+    outs = {}
+    for k in ("mfma", "valu"):
+        os.environ["CLD_DECODE_KERNEL"] = k
+        try:
+            outs[k] = eng_jitter.decode(z, cond, cs, descaled_output=True, want_act=True)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["CLD_DECODE_KERNEL"]
+    wd = O.to_torch(synth.make_decoder_weights(0))
+    torch.set_num_threads(8)
+    act_ref = O.lstm_decode(wd, z, cond)
+    traj_ref = O.decode(wd, z, cond, cs, descaled_output=True)
+    for k in ("mfma", "valu"):
+        traj, act = outs[k]
+        assert (act.cpu() - act_ref).abs().max().item() <= 2e-5, k
+        assert (traj.cpu() - traj_ref).abs().max().item() <= 1e-4, k
+    assert (outs["mfma"][0] - outs["valu"][0]).abs().max().item() <= 1e-4
