@@ -92,6 +92,9 @@ def main():
     eng = Engine(n_timesteps=n, device=dev, precision=args.precision)
     eng.load_state_dict(synth.make_unet_weights(0))            # PyTorch-default-like random init (no checkpoint ships)
     eng.load_state_dict(synth.make_decoder_weights(0))
+    has_encoder = bool(args.closed_loop)
+    if has_encoder:
+        eng.load_state_dict(synth.make_encoder_weights(0))
     if not args.no_context:
         eng.load_state_dict(synth.make_context_weights(0))
     eng.finalize()
@@ -136,6 +139,10 @@ def main():
                 x0, _, _ = eng.sample(x_T, cnd, noise=noise, non_cond=non_cond, guidance_w=args.cfg_w,
                                       want_x1=False, want_logp=False, guidance=None if guidance is None else dict(guidance, curr_states=c))
                 traj = eng.decode(x0, cnd, c, descaled_output=True)
+                if has_encoder:   # "VAE encode" stage of configs[4]: the plan re-encoded to its latent posterior (context_utils.py:64-70
+                    sa = eng.state_to_state_and_action(traj[..., :2].contiguous(), traj[..., 3:4].contiguous(), c[:, 2].contiguous(),
+                                                       scaled_output=True)                      # -> lstm_vae.py:87-99); result unused
+                    eng.traj2z(sa, cnd, noise=None)
                 if distributed:
                     gather_trajectories(traj, gathered)
                 world, c = eng.world_step(traj, world[:, :2].contiguous(), world[:, 2].contiguous(), 4)
@@ -200,7 +207,9 @@ def main():
                                "(DDPM ancestral loop of the reference), latent seq 52 x 4, cond 256, "
                                + (f"CFG w={args.cfg_w} (2 U-Net passes per step)" if args.cfg_w else "CFG off")
                                + ("; target-speed guidance gradient every step" if args.guide else "") + "; "
-                               "+ LSTM decode + unicycle roll-out" + ("; RCCL all-gather of trajectories" if distributed else ""),
+                               "+ LSTM decode + unicycle roll-out" + ("; + VAE encode of the plan, kinematic world update" if args.closed_loop else "")
+                               + ("; + ContextEncoder per sim step" if (args.closed_loop and use_ctx) else "")
+                               + ("; RCCL all-gather of trajectories" if distributed else ""),
                    "scenes_per_gpu": args.scenes, "agents_per_scene": args.agents, "agents_per_gpu": B,
                    "denoise_steps": n, "cfg_guidance_w": args.cfg_w, "unet_passes_per_step": 2 if args.cfg_w else 1,
                    "weights": "random init (synth seed 0)"},

@@ -931,40 +931,6 @@ int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx
     return CLD_OK;
 }
 
-int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* cond, int32_t steps, float* x0,
-               float* x1, float* logp, int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_common(h, "cld_sample", B, 0, workspace, workspace_bytes);
-    if (rc) return rc;
-    if (!x_T || !cond) return fail(h, CLD_ERR_ARG, "cld_sample: null pointer");
-    if (steps != loop_steps(h))
-        return fail(h, CLD_ERR_ARG, "cld_sample: steps must equal len(range(0, n_timesteps, stride)) = " + std::to_string(loop_steps(h)));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int bp = pad16(B);
-    Ws w = carve(workspace, bp);
-    HIPCK(h, launch_pack_latent(x_T, w.xw, B, bp, s));
-    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
-    for (int it = 0; it < steps; ++it) {
-        const int i = (steps - 1 - it) * h->stride;
-        HIPCK(h, run_unet(h, w, w.xw, i, bp, s));
-        const float sigma = std::exp(0.5f * h->plvc[i]);
-        HeadArgs a{};
-        a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
-        a.z = noise ? noise + (size_t)it * B * T * D : nullptr;
-        a.seed = seed; a.step_salt = (unsigned long long)it;
-        a.x_out = w.xw;                                   // in place: each thread rewrites the row it read
-        a.mean_out = (i == 0) ? w.meanb : nullptr;
-        a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
-        a.sg = (i == 0) ? 0.f : sigma;
-        HIPCK(h, launch_head(a, s));
-        if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
-        if (i == 0) {
-            if (x0) HIPCK(h, launch_unpack(w.xw, x0, B, s));
-            if (logp) HIPCK(h, launch_logprob(w.xw, w.meanb, sigma, logp, B, s));
-        }
-    }
-    return CLD_OK;
-}
-
 static int sample_impl(cld_handle h, const char* fn, const float* x_T, const float* noise, const float* cond,
                        const float* non_cond, float guidance_w, const cld_guidance* gd, int32_t steps, float* x0, float* x1,
                        float* logp, int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1032,6 +998,12 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
         }
     }
     return CLD_OK;
+}
+
+int cld_sample(cld_handle h, const float* x_T, const float* noise, const float* cond, int32_t steps, float* x0,
+               float* x1, float* logp, int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
+    return sample_impl(h, "cld_sample", x_T, noise, cond, nullptr, 0.f, nullptr, steps, x0, x1, logp, B, seed, workspace,
+                       workspace_bytes, stream);
 }
 
 int cld_sample_cfg(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
