@@ -662,8 +662,162 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncoderWeights w, con
         __syncthreads();
     }
 }
+// MFMA formulation of the encoder (same structure as decode_mfma_kernel: 16 agents per workgroup, wave w owns units
+// 16w..16w+15 and their four gate N-tiles, cell update in registers); the 6-dim input takes two k-steps (dims 0-3, then 4-5
+// padded with zeros); the mu / logvar heads are eight 64-long dot products per (agent, step), reduced over the 16 lanes of a
+// unit block and over the four waves through a small parity-buffered LDS array.
+__global__ __launch_bounds__(256) void encode_mfma_kernel(const EncoderWeights w, const float* __restrict__ x6,
+                                                          const float* __restrict__ cond, const float* __restrict__ noise,
+                                                          float* __restrict__ z, float* __restrict__ mu_out,
+                                                          float* __restrict__ lv_out, int B) {
+    constexpr int AG = 16, HS = 68;
+    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];
+    __shared__ __attribute__((aligned(16))) float xin[AG][312];
+    __shared__ __attribute__((aligned(16))) float condm[AG][256];
+    __shared__ float parts[2][8][4][AG];     // [step parity][head][wave][agent]
+    __shared__ float head[AG][52][8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, rb = lane >> 4;
+    const int u = 16 * wv + n;
+    float wh[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { wh[k] = w.w_mu[k * 64 + u]; wh[4 + k] = w.w_lv[k * 64 + u]; }
+    float f_hh0[4][4][4], f_ih1[4][4][4], f_hh1[4][4][4], f_ih0a[4], f_ih0b[4], fb0[4], fb1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = 64 * g + 16 * wv + n;
+        f_ih0a[g] = w.w_ih0[col * 6 + rb];
+        f_ih0b[g] = rb < 2 ? w.w_ih0[col * 6 + 4 + rb] : 0.f;
+        fb0[g] = w.b0[col];
+        fb1[g] = w.b1[col];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const v4f x0 = *reinterpret_cast<const v4f*>(w.w_hh0 + col * 64 + 16 * jj + 4 * rb);
+            const v4f x1 = *reinterpret_cast<const v4f*>(w.w_ih1 + col * 64 + 16 * jj + 4 * rb);
+            const v4f x2 = *reinterpret_cast<const v4f*>(w.w_hh1 + col * 64 + 16 * jj + 4 * rb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f_hh0[g][jj][e] = x0[e]; f_ih1[g][jj][e] = x1[e]; f_hh1[g][jj][e] = x2[e]; }
+        }
+    }
+    const int ngroups = (B + AG - 1) / AG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * AG;
+        auto agent = [&](int ag) { return (b0 + ag < B) ? b0 + ag : B - 1; };
+        for (int i = tid; i < AG * 256; i += 256) condm[i >> 8][i & 255] = cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
+        for (int i = tid; i < AG * 312; i += 256) xin[i / 312][i % 312] = x6[(size_t)agent(i / 312) * 312 + i % 312];
+        __syncthreads();
+        for (int i = tid; i < AG * 64; i += 256) {
+            const int ag = i >> 6, uu = i & 63;
+            float s = w.b_c2h[uu];
+            const float* wr = w.w_c2h + uu * 256;
+            for (int k = 0; k < 256; ++k) s = fmaf(condm[ag][k], wr[k], s);
+            hs[0][0][ag][uu] = s;
+            hs[1][0][ag][uu] = s;
+        }
+        float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int t = 0; t < 52; ++t) {
+            const int pr = t & 1;
+            v4f acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = v4f{fb0[g], fb0[g], fb0[g], fb0[g]};
+            {
+                const float xa = xin[n][6 * t + rb];
+                const float xb = rb < 2 ? xin[n][6 * t + 4 + rb] : 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f_ih0a[g], acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, f_ih0b[g], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_hh0[g][jj][e], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = fsig_m(acc[0][r]), fg = fsig_m(acc[1][r]), gg = ftanh_m(acc[2][r]), og = fsig_m(acc[3][r]);
+                const float c = fg * c0[r] + ig * gg;
+                c0[r] = c;
+                hs[0][pr ^ 1][4 * rb + r][u] = og * ftanh_m(c);
+            }
+            __syncthreads();
+            if (t > 0 && tid < AG * 8) {      // heads of step t-1: its partials are complete (barrier above) and not yet overwritten
+                const int ag = tid >> 3, k = tid & 7, q = (t - 1) & 1;
+                head[ag][t - 1][k] = parts[q][k][0][ag] + parts[q][k][1][ag] + parts[q][k][2][ag] + parts[q][k][3][ag] +
+                                     (k < 4 ? w.b_mu[k] : w.b_lv[k - 4]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = v4f{fb1[g], fb1[g], fb1[g], fb1[g]};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][n][16 * jj + 4 * rb]);
+                const v4f hb = *reinterpret_cast<const v4f*>(&hs[1][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[g][jj][e], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[g][jj][e], acc[g], 0, 0, 0);
+                }
+            }
+            float hp[8][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = fsig_m(acc[0][r]), fg = fsig_m(acc[1][r]), gg = ftanh_m(acc[2][r]), og = fsig_m(acc[3][r]);
+                const float c = fg * c1[r] + ig * gg;
+                c1[r] = c;
+                const float hn = og * ftanh_m(c);
+                hs[1][pr ^ 1][4 * rb + r][u] = hn;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) hp[k][r] = hn * wh[k];
+            }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hp[k][r] += __shfl_xor(hp[k][r], o);
+            if (n == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) parts[pr][k][wv][4 * rb + r] = hp[k][r];
+            }
+            __syncthreads();
+        }
+        if (tid < AG * 8) {                   // heads of the last step
+            const int ag = tid >> 3, k = tid & 7, q = 51 & 1;
+            head[ag][51][k] = parts[q][k][0][ag] + parts[q][k][1][ag] + parts[q][k][2][ag] + parts[q][k][3][ag] +
+                              (k < 4 ? w.b_mu[k] : w.b_lv[k - 4]);
+        }
+        __syncthreads();
+        for (int i = tid; i < AG * 208; i += 256) {
+            const int ag = i / 208, r = i % 208, t = r >> 2, k = r & 3, b = b0 + ag;
+            if (b >= B) continue;
+            const float m = head[ag][t][k], lv = head[ag][t][4 + k];
+            if (mu_out) mu_out[(size_t)b * 208 + r] = m;
+            if (lv_out) lv_out[(size_t)b * 208 + r] = lv;
+            if (z) z[(size_t)b * 208 + r] = m + (noise ? noise[(size_t)b * 208 + r] : 0.f) * expf(0.5f * lv);
+        }
+        __syncthreads();
+    }
+}
+
 hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* cond, const float* noise, float* z,
                          float* mu, float* logvar, int B, hipStream_t s) {
+    const char* force = getenv("CLD_ENCODE_KERNEL");      // experiments only: valu | mfma
+    const bool mfma = force ? force[0] == 'm' : B >= 256;
+    if (mfma) {
+        const int groups = (B + 15) / 16;
+        hipLaunchKernelGGL(encode_mfma_kernel, dim3(groups < 1024 ? groups : 1024), dim3(256), 0, s, w, x6, cond, noise, z, mu,
+                           logvar, B);
+        return hipGetLastError();
+    }
     const int grid = B < 2048 ? B : 2048;
     hipLaunchKernelGGL(encode_kernel, dim3(grid), dim3(256), 0, s, w, x6, cond, noise, z, mu, logvar, B);
     return hipGetLastError();

@@ -786,3 +786,32 @@ def test_decode_mfma_kernel_vs_oracle_and_valu(eng_jitter):
         assert (act.cpu() - act_ref).abs().max().item() <= 2e-5, k
         assert (traj.cpu() - traj_ref).abs().max().item() <= 1e-4, k
     assert (outs["mfma"][0] - outs["valu"][0]).abs().max().item() <= 1e-4
+
+
+def test_encode_mfma_kernel_vs_oracle_and_valu():
+    """The MFMA formulation of the VAE encoder (from 256 agents up) at B = 300 (ragged last tile): z / mu / logvar against the
+    oracle (2e-5, the encoder bar) and against the one-agent-per-workgroup kernel."""
+    import os
+    from cld_amd.engine import Engine
+    from oracle import cld_oracle as O
+    e = Engine(n_timesteps=10, device="cuda:0")
+    for sd in (synth.make_unet_weights(0), synth.make_encoder_weights(0)):
+        e.load_state_dict(sd)
+    e.finalize()
+    B = 300
+    cond = torch.from_numpy(synth.make_inputs(B, 61)["cond_feat"])
+    x6 = torch.from_numpy(synth.normal(61, "x6", (B, 52, 6)))
+    nz = torch.from_numpy(synth.normal(61, "nz", (B, 52, 4)))
+    outs = {}
+    for k in ("mfma", "valu"):
+        os.environ["CLD_ENCODE_KERNEL"] = k
+        try:
+            outs[k] = e.traj2z(x6, cond, nz)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["CLD_ENCODE_KERNEL"]
+    torch.set_num_threads(8)
+    ref = O.traj2z(O.to_torch(synth.make_encoder_weights(0)), x6, cond, nz)
+    for k in ("mfma", "valu"):
+        for got, want in zip(outs[k], ref):
+            assert (got.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), k
