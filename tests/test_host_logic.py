@@ -211,3 +211,11 @@ def test_integration_doc_names_every_entry_point():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = [s for s in set(re.findall(r"\b(cld_[a-z_0-9]+)\s*\(", hdr)) if s not in doc]
     assert not missing, missing
+
+
+def test_bench_cli_parses_without_a_gpu():
+    """bench.py must import and parse its flags on a CPU-only host (the driver builds here before benching on the GPU box)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    for flag in ("--gpus", "--steps", "--warmup", "--cfg-w", "--guide", "--closed-loop", "--precision", "--no-context"):
+        assert flag in out.stdout
