@@ -284,7 +284,20 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
         if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c))
             return set(32, 4, 2);     // (64-channel chunks with this tiling: 918k vs 949k step.agent/s, not built)
     }
-    if (l.has_b) return set(32, 2, 2);
+    if (l.has_b) {
+        set(32, 2, 2);
+        // half-height tiles (104 rows: 8 / 4 / 2 agents) when full-height tiling B would put fewer than two workgroups on
+        // every CU: twice the workgroups, each with half the M-tiles
+        static const char* th = getenv("CLD_TILING_HALF");        // experiments: "0" never, "1" wherever an instance exists
+        const long wgs_b = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 32);
+        ConvGeom hg = *g; hg.half = 1;
+        // measured (sample-only step.agent/s, half vs full): B = 64: 150k vs 86k, 256: 590k vs 344k, 512: 813k vs 680k,
+        // 768: 845k vs 745k, 1,536: 830k vs 805k; the one case that prefers full tiles is exactly one full workgroup per CU
+        // on the narrow layers of a >= 1,024-agent batch (B = 1,024: 945k vs 935k)
+        const bool want = wgs_b < 512 && !(wgs_b == 256 && b_pad >= 1024);
+        if (!(th && th[0] == '0') && ((th && th[0] == '1') || want) && conv_geom_supported(hg)) g->half = 1;
+        return true;
+    }
     return false;
 }
 
@@ -586,7 +599,7 @@ int cld_finalize(cld_handle h, void* stream) {
             UP(l.beta, *getw(h, gn_name + ".bias"));
         }
         l.c_out = c_out; l.c1_real = c1_real; l.c1_pad = c1_pad; l.c2 = c2; l.ly = ly; l.off0 = off0; l.orow0 = orow0;
-        l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0, ain, aout};
+        l.g = ConvGeom{L_in, lm, stride, ntaps, 32, 4, 1, epi, c_out / 8, ostr, c1_real < 32 ? 1 : 0, ain, aout, 0};
         if (c2 > 0 && c2 != c1_real) return fail(h, CLD_ERR_ARG, "cld_finalize: concatenated sources must have equal channel counts");
         ConvGeom t = l.g;
         if (ain == 1 && stride == 1) t.kc = 64;

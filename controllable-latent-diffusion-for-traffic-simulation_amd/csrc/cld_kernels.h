@@ -61,6 +61,7 @@ struct ConvGeom {
     int padc;     // 1: the input has fewer real channels than one K chunk (the 4-channel latent)
     int ain;      // activation format of the input: 0 = fp32, 1 = S22 (fp16 hi/lo planes, split-precision loop)
     int aout;     // activation format of the output and of the residual
+    int half;     // 1: half-height tiles (104 GEMM rows per workgroup instead of 208), exact-fp32 tiling B only
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s);
 bool conv_geom_supported(const ConvGeom& g);

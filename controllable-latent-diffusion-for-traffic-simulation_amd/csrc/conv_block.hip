@@ -109,9 +109,15 @@ __device__ __forceinline__ void s22_encode(const float (&v)[4], h4& hi, h4& lo) 
 // split-precision loop: products hi*hi + hi*lo + lo*hi on the fp16 MFMA (weights pre-split and pre-scaled on the
 // host), fp32 accumulation -- measured indistinguishable from the exact-fp32 loop on this network
 // (tests/tools/emulate_split.py) at ~3.9x its in-loop rate (scripts/ubench/mfma_issue.hip, V5).
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const int bx, const int by) {
+    // HM = 1: half-height tiles -- 104 GEMM rows (8 / 4 / 2 agents at L = 13 / 26 / 52) = 6.5 M-tiles, the last one half
+    // empty (its upper 8 rows are computed on row 0's operands and never read back); twice the workgroups of a full tile,
+    // taken when a full-height launch would leave the chip under two workgroups per CU
+    constexpr int MT = HM ? 104 : 208;
+    constexpr int NMT = HM ? 7 : 13;
     constexpr bool SPLIT = AIN == 1;
+    static_assert(!SPLIT || HM == 0, "half-height tiles: exact-fp32 loop only");
     static_assert(!SPLIT || (KS == 1 && KC % 32 == 0 && PADC == 0), "split-precision loop: whole 32-channel MFMA groups, no K split");
     constexpr int MG = KC / 32;            // split mode: 32-channel MFMA groups per chunk
     constexpr int NTHR = 64 * NWN * KS;
@@ -230,7 +236,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     int aoffy[SPLIT ? NMT : 1];                         // split mode: aoff = plane at +0/+16 for even taps, aoffy = the other plane
 #pragma unroll
     for (int m = 0; m < NMT; ++m) {
-        const int r = 16 * m + (lane & 15);
+        int r = 16 * m + (lane & 15);
+        if (HM && r >= MT) r = 0;                       // dummy rows of the half-empty last M-tile
         const int a = r / LM;
         const int j = r - a * LM;
         if (SPLIT) {
@@ -451,7 +458,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     // ---- accumulators -> LDS tiles [KS][208][OP] (aliasing the A images): every K-split rank stores its own
     //      partial tile, one barrier, and the epilogue threads add the KS partials while reading ----
     float* O = lds;
-    constexpr int OTILE = MT * OP;
+    constexpr int OTILE = 16 * NMT * OP;               // (= MT rows for full tiles; the half tile's last M-tile has 8 dummy rows)
     static_assert((size_t)KS * OTILE * 4 <= 160 * 1024, "partial output tiles must fit in LDS (the launcher sizes the allocation)");
     {
         const int col = nw * 16 + (lane & 15);
@@ -550,10 +557,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 
 // register budget: 256 (two waves per SIMD) for the exact-fp32 loop, which needs the partner wave to hide its non-MFMA
 // issue; 512 for the split-precision loop, which keeps two full fragment sets (hi + lo) in flight and is not MFMA-bound
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 __global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_block_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT>(p, lds, blockIdx.x, blockIdx.y);
+    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>(p, lds, blockIdx.x, blockIdx.y);
 }
 
 // Two launches that do not depend on each other and share a grid shape, merged into one: blockIdx.z picks the
@@ -563,12 +570,12 @@ __global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_block_ke
 // NOT saved -- the second role's workgroups still form their own generation on each CU.
 struct ConvPairArgs { ConvArgs a, b; };
 template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC,
-          int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT>
+          int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT, int HM>
 __global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_pair_kernel(const ConvPairArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (interleaving the two roles along x, alone or in XCD-balanced groups of 8, measured 9 % slower end to end)
-    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC, AIN, AOUT>(p.a, lds, blockIdx.x, blockIdx.y);
-    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC, AIN, AOUT>(p.b, lds, blockIdx.x, blockIdx.y);
+    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC, AIN, AOUT, HM>(p.a, lds, blockIdx.x, blockIdx.y);
+    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC, AIN, AOUT, HM>(p.b, lds, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,14 +587,14 @@ static size_t g_lds_floor = 0;
 void set_lds_floor(size_t bytes) { g_lds_floor = bytes; }
 static inline size_t lds_request(size_t need) { return g_lds_floor > need ? (g_lds_floor < 160 * 1024 ? g_lds_floor : 160 * 1024) : need; }
 
-template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT>
+template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
-    constexpr int AG = MT / LM;
+    constexpr int AG = (HM ? 104 : 208) / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);   // image + dump row
-    constexpr int OTILE = KS * MT * (16 * NWN + 4);              // the epilogue's partial output tiles alias the A images
+    constexpr int OTILE = KS * 16 * (HM ? 7 : 13) * (16 * NWN + 4);   // the epilogue's partial output tiles alias the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
-    auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT>;
+    auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -600,13 +607,13 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT>
+template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT, int HM>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_pad, hipStream_t s) {
-    constexpr int AG = MT / LM;
+    constexpr int AG = (HM ? 104 : 208) / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);
-    constexpr int OTILE = KS * MT * (16 * NWN + 4);
+    constexpr int OTILE = KS * 16 * (HM ? 7 : 13) * (16 * NWN + 4);
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
-    auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT>;
+    auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT, HM>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -622,39 +629,46 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
 
 // pairs: (L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT), stride 1 on both sides
 #define CLD_PAIR_INSTANCES(X)                                         \
-    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
-    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
-    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
-    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
-    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
-    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
-    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
-    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)        \
-    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
-    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0)         \
-    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)           \
-    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)           \
-    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0)            \
-    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0) \
-    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 1)   \
-    X(26, 26, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
-    X(13, 13, 64, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
-    X(13, 13, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)  \
-    X(26, 26, 64, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1)   \
-    X(13, 13, 64, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)     \
-    X(26, 26, 64, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1)
+    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
+    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
+    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
+    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
+    X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
+    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
+    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
+    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 1, 0) \
+    X(26, 26, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
+    X(13, 13, 64, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
+    X(13, 13, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
+    X(26, 26, 64, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
+    X(13, 13, 64, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1, 0) \
+    X(26, 26, 64, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 1, 1, 0)
 
 static inline bool pair_is(const ConvGeom& a, const ConvGeom& b, int l_in, int lm, int kc, int nwn, int ks, int gs, int ostr,
-                           int padc, int ntaps_a, int epi_a, int ntaps_b, int epi_b, int ain, int aout) {
+                           int padc, int ntaps_a, int epi_a, int ntaps_b, int epi_b, int ain, int aout, int half) {
     auto common = [&](const ConvGeom& g) {
         return g.l_in == l_in && g.lm == lm && g.stride == 1 && g.kc == kc && g.nwn == nwn && g.ks == ks && g.gs == gs &&
-               g.ostr == ostr && g.padc == padc && g.ain == ain && g.aout == aout;
+               g.ostr == ostr && g.padc == padc && g.ain == ain && g.aout == aout && g.half == half;
     };
     return common(a) && common(b) && a.ntaps == ntaps_a && a.epi == epi_a && b.ntaps == ntaps_b && b.epi == epi_b;
 }
 
 bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b) {
-#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14) if (pair_is(a, b, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14)) return true;
+#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15) if (pair_is(a, b, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15)) return true;
     CLD_PAIR_INSTANCES(X)
 #undef X
     return false;
@@ -662,9 +676,9 @@ bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b) {
 
 hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s) {
     if (a.c_out != b.c_out) return hipErrorInvalidValue;
-#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14) \
-    if (pair_is(ga, gb, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14)) \
-        return launch_pair_inst<c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14>(a, b, b_pad, s);
+#define X(c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15) \
+    if (pair_is(ga, gb, c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15)) \
+        return launch_pair_inst<c1, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11, c12, c13, c14, c15>(a, b, b_pad, s);
     CLD_PAIR_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;
@@ -677,73 +691,89 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
 //   (the template also supports KC 64 / NWN 2 / KS 4, measured slower than B, and NWN 8 / KS 1 -- 128 columns in an
 //    8-wave workgroup -- measured equal to A at 2,048 and 4,096 agents; neither is built)
 #define CLD_CONV_INSTANCES(X)                            \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
-    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0)         \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 0)            \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0)            \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
-    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
-    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
-    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
-    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
-    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
-    X(13, 13, 1, 5, 32, 4, 2, EPI_GN_MISH, 32, 1, 0, 0, 0)        \
-    X(26, 26, 1, 5, 32, 4, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
-    X(52, 52, 1, 5, 32, 4, 2, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
-    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
-    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0)        \
-    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
-    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0)         \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0)            \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0)            \
-    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0)           \
-    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0)           \
-    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 0, 0)           \
-    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0)           \
-    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0)           \
-    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0)           \
-    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0)            \
-    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0)            \
-    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0)            \
-    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0)           \
-    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 0, 0)           \
-    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0)           \
-    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 0, 0)            \
-    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0) \
-    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1)   \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 1)      \
-    X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
-    X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0)   \
-    X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
-    X(13, 13, 1, 5, 64, 4, 1, EPI_GN_MISH, 32, 1, 0, 1, 1)  \
-    X(13, 13, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1)  \
-    X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1)   \
-    X(26, 26, 1, 1, 64, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
-    X(13, 13, 1, 1, 64, 4, 1, EPI_BIAS, 32, 1, 0, 1, 1)     \
-    X(13, 13, 1, 1, 64, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
-    X(26, 26, 1, 1, 64, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
-    X(52, 26, 2, 3, 32, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1)      \
-    X(26, 13, 2, 3, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1)     \
-    X(13, 13, 1, 2, 64, 4, 1, EPI_BIAS, 16, 2, 0, 1, 1)     \
-    X(26, 26, 1, 2, 64, 4, 1, EPI_BIAS, 8, 2, 0, 1, 1)
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 1) \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 0, 0) \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 0) \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 1) \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 5, 32, 4, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 5, 32, 4, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
+    X(52, 52, 1, 5, 32, 4, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 1) \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
+    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
+    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
+    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
+    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 0, 0, 0) \
+    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 0) \
+    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 1) \
+    X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 0, 0, 0) \
+    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 0) \
+    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 1) \
+    X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1, 0) \
+    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 1, 0) \
+    X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1, 0) \
+    X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0, 0) \
+    X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1, 0) \
+    X(13, 13, 1, 5, 64, 4, 1, EPI_GN_MISH, 32, 1, 0, 1, 1, 0) \
+    X(13, 13, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1, 0) \
+    X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1, 0) \
+    X(26, 26, 1, 1, 64, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1, 0) \
+    X(13, 13, 1, 1, 64, 4, 1, EPI_BIAS, 32, 1, 0, 1, 1, 0) \
+    X(13, 13, 1, 1, 64, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1, 0) \
+    X(26, 26, 1, 1, 64, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1, 0) \
+    X(52, 26, 2, 3, 32, 4, 1, EPI_BIAS, 8, 1, 0, 1, 1, 0) \
+    X(26, 13, 2, 3, 32, 4, 1, EPI_BIAS, 16, 1, 0, 1, 1, 0) \
+    X(13, 13, 1, 2, 64, 4, 1, EPI_BIAS, 16, 2, 0, 1, 1, 0) \
+    X(26, 26, 1, 2, 64, 4, 1, EPI_BIAS, 8, 2, 0, 1, 1, 0)
 
 static inline bool geom_is(const ConvGeom& g, int l_in, int lm, int stride, int ntaps, int kc, int nwn, int ks,
-                           int epi, int gs, int ostr, int padc, int ain, int aout) {
+                           int epi, int gs, int ostr, int padc, int ain, int aout, int half) {
     return g.l_in == l_in && g.lm == lm && g.stride == stride && g.ntaps == ntaps && g.kc == kc &&
            g.nwn == nwn && g.ks == ks && g.epi == epi && g.gs == gs && g.ostr == ostr && g.padc == padc &&
-           g.ain == ain && g.aout == aout;
+           g.ain == ain && g.aout == aout && g.half == half;
 }
 
 bool conv_geom_supported(const ConvGeom& g) {
-#define X(a, b, c, d, e, f, k, h, i, j, l, m, n) if (geom_is(g, a, b, c, d, e, f, k, h, i, j, l, m, n)) return true;
+#define X(a, b, c, d, e, f, k, h, i, j, l, m, n, o) if (geom_is(g, a, b, c, d, e, f, k, h, i, j, l, m, n, o)) return true;
     CLD_CONV_INSTANCES(X)
 #undef X
     return false;
 }
 
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
-#define X(a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_) \
-    if (geom_is(g, a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_)) return launch_inst<a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_>(a, b_pad, s);
+#define X(a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_, o_) \
+    if (geom_is(g, a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_, o_)) return launch_inst<a_, b_, c_, d_, e_, f_, k_, h_, i_, j_, l_, m_, n_, o_>(a, b_pad, s);
     CLD_CONV_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;
