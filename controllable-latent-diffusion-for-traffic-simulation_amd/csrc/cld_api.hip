@@ -286,16 +286,27 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     }
     if (l.has_b) {
         set(32, 2, 2);
-        // half-height tiles (104 rows: 8 / 4 / 2 agents) when full-height tiling B would put fewer than two workgroups on
-        // every CU: twice the workgroups, each with half the M-tiles
-        static const char* th = getenv("CLD_TILING_HALF");        // experiments: "0" never, "1" wherever an instance exists
+        // Tile height (HM = 0 / 1 / 2: 208 / 104 / 52 GEMM rows = 13 / 7 / 4 M-tiles per wave): shorter tiles multiply the
+        // workgroups and shorten each one's serial MFMA chain, at the price of a partly empty last M-tile.  Cost model (fits
+        // the measured sweep B = 8 .. 2,048): a CU holds two workgroups at a time, so a launch takes ceil(n / 256) rounds of
+        // NMT M-tiles, at ~0.85 of the MFMA rate when a CU only ever sees one wave per SIMD and ~0.92 otherwise; near-ties go
+        // to the taller tile from 1,024 agents (narrow layers there: 945k vs 935k step.agent/s) and to the shorter one below
+        // (B = 512: 817k vs 795k).  Sample latency 74 -> 31 ms at B <= 128;
+        // throughput x2.4 at B = 64 (208k), x1.9 at 256 (650k), x1.2 at 512 (817k), x1.14 at 768.
+        static const char* th = getenv("CLD_TILING_HALF");        // experiments: "0" full tiles only, "1" / "2" force that height
         const long wgs_b = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 32);
-        ConvGeom hg = *g; hg.half = 1;
-        // measured (sample-only step.agent/s, half vs full): B = 64: 150k vs 86k, 256: 590k vs 344k, 512: 813k vs 680k,
-        // 768: 845k vs 745k, 1,536: 830k vs 805k; the one case that prefers full tiles is exactly one full workgroup per CU
-        // on the narrow layers of a >= 1,024-agent batch (B = 1,024: 945k vs 935k)
-        const bool want = wgs_b < 512 && !(wgs_b == 256 && b_pad >= 1024);
-        if (!(th && th[0] == '0') && ((th && th[0] == '1') || want) && conv_geom_supported(hg)) g->half = 1;
+        int best = 0;
+        double best_cost = 1e30;
+        for (int hm = 0; hm <= 2; ++hm) {
+            ConvGeom tg = *g; tg.half = hm;
+            if (!conv_geom_supported(tg)) continue;
+            if (th && th[0] != '0' + hm && (th[0] == '0' || th[0] == '1' || th[0] == '2')) continue;
+            const long n = wgs_b << hm, rounds = (n + 255) / 256;
+            const int nmt = ((208 >> hm) + 15) / 16;
+            const double cost = (double)rounds * nmt / (rounds == 1 ? 0.85 : 0.92);
+            if (cost < best_cost * (b_pad >= 1024 ? 0.97 : 1.0)) { best_cost = cost; best = hm; }      // near-ties: taller tile from 1,024 agents
+        }
+        g->half = best;
         return true;
     }
     return false;

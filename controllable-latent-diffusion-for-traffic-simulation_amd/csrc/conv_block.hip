@@ -114,10 +114,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     // HM = 1: half-height tiles -- 104 GEMM rows (8 / 4 / 2 agents at L = 13 / 26 / 52) = 6.5 M-tiles, the last one half
     // empty (its upper 8 rows are computed on row 0's operands and never read back); twice the workgroups of a full tile,
     // taken when a full-height launch would leave the chip under two workgroups per CU
-    constexpr int MT = HM ? 104 : 208;
-    constexpr int NMT = HM ? 7 : 13;
+    constexpr int MT = 208 >> HM;                       // HM = 2: quarter-height tiles, 52 rows = 3.25 M-tiles (4 / 2 / 1 agents)
+    constexpr int NMT = (MT + 15) / 16;
     constexpr bool SPLIT = AIN == 1;
-    static_assert(!SPLIT || HM == 0, "half-height tiles: exact-fp32 loop only");
+    static_assert(!SPLIT || HM == 0, "half- / quarter-height tiles: exact-fp32 loop only");
     static_assert(!SPLIT || (KS == 1 && KC % 32 == 0 && PADC == 0), "split-precision loop: whole 32-channel MFMA groups, no K split");
     constexpr int MG = KC / 32;            // split mode: 32-channel MFMA groups per chunk
     constexpr int NTHR = 64 * NWN * KS;
@@ -589,9 +589,9 @@ static inline size_t lds_request(size_t need) { return g_lds_floor > need ? (g_l
 
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
-    constexpr int AG = (HM ? 104 : 208) / LM;
+    constexpr int AG = (208 >> HM) / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);   // image + dump row
-    constexpr int OTILE = KS * 16 * (HM ? 7 : 13) * (16 * NWN + 4);   // the epilogue's partial output tiles alias the A images
+    constexpr int OTILE = KS * 16 * (((208 >> HM) + 15) / 16) * (16 * NWN + 4);   // the epilogue's partial output tiles alias the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>;
@@ -609,9 +609,9 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
 
 template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT, int HM>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_pad, hipStream_t s) {
-    constexpr int AG = (HM ? 104 : 208) / LM;
+    constexpr int AG = (208 >> HM) / LM;
     constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);
-    constexpr int OTILE = KS * 16 * (HM ? 7 : 13) * (16 * NWN + 4);
+    constexpr int OTILE = KS * 16 * (((208 >> HM) + 15) / 16) * (16 * NWN + 4);
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT, HM>;
     static bool attr_done = false;
@@ -632,24 +632,31 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
     X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
     X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
     X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
     X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
+    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
     X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
+    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 2) \
     X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
+    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 2) \
     X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 1, 0) \
     X(26, 26, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
     X(13, 13, 64, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
@@ -694,52 +701,68 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 1) \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 2) \
     X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 1) \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 2) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 1) \
+    X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 2) \
     X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 2) \
     X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 2) \
     X(13, 13, 1, 5, 32, 4, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 4, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 4, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 2) \
     X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 2) \
     X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
+    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 2) \
     X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 2) \
     X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 2) \
     X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 2) \
     X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 2) \
     X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
+    X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 2) \
     X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
+    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 2) \
     X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 0, 0, 0) \
     X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 0) \
     X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 1) \
+    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 2) \
     X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 0, 0, 0) \
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 0) \
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 1) \
+    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 2) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1, 0) \
     X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 1, 0) \
     X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1, 0) \
