@@ -186,7 +186,7 @@ def main():
                     "frac": round(ach / peak, 4), "traffic": pmc_traffic(B) if not split else None,
                     "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                    else "v_mfma_f32_16x16x4_f32 dense peak"),
-                    "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0> (Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; "
+                    "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0,0> (Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; "
                                "8 launches per U-Net evaluation -- 7 with 256 input channels, 1 with 128 -- every 10th evaluation timed; "
                                "tiling picked by batch size)"
                                % ("4,1" if (B + 15) // 16 * 4 * 4 >= 2048 else ("4,2" if B >= 1024 else "2,2"))),
@@ -325,9 +325,9 @@ def cpu_baseline(B):
     with torch.no_grad():
         O.ddpm_step(w, s, x[:64], cond[:64], 99, z[:64])     # warm-up
         t0 = time.perf_counter()
-        O.ddpm_step(w, s, x, cond, 99, z)                    # probe: sizes the bounded sample (~12 s of CPU work)
+        O.ddpm_step(w, s, x, cond, 99, z)                    # probe: sizes the bounded sample (~15 s of CPU work)
         probe = time.perf_counter() - t0
-        CPU_STEPS = max(1, min(60, int(12.0 / max(probe, 1e-3))))
+        CPU_STEPS = max(1, min(99, int(15.0 / max(probe, 1e-3))))
         t0 = time.perf_counter()
         for k in range(CPU_STEPS):
             x, _, _ = O.ddpm_step(w, s, x, cond, 98 - k, z)

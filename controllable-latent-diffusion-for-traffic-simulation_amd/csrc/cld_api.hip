@@ -275,14 +275,20 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
     if (l.has_a && (waves_a >= 2048 || !l.has_b)) return set(32, 4, 1);
     // tiling C for the 256-channel k5 blocks between 1,024 and 2,047 agents: 8-wave workgroups (64 columns x 2-way K split),
-    // one per CU -- the same two waves per SIMD as B with half the A-image staging per MFMA (+1.4 % end to end at B = 1,024)
+    // one per CU -- the same two waves per SIMD as B with half the A-image staging per MFMA (+1.4 % end to end at B = 1,024).
+    // One C workgroup is two B workgroups' work on a CU, so in the units of the tile-height model below it costs
+    // ceil(wgs_c / 256) * 2 * 13 / 0.92 / 1.014; it competes with the B heights on that cost (B = 1,536: 384 C workgroups are
+    // 1.5 rounds of the chip, 768 B workgroups exactly 3 half-rounds).
+    double cost_c = 1e30;
     {
         ConvGeom c = l.g; c.kc = 32; c.nwn = 4; c.ks = 2;
         const long wgs_c = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64);
         static const char* tc = getenv("CLD_TILING_C");       // experiments: "0" = never, "all" = every layer shape that has an instance
         const bool widest_only = !(tc && tc[0] == 'a');
-        if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c))
-            return set(32, 4, 2);     // (64-channel chunks with this tiling: 918k vs 949k step.agent/s, not built)
+        if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c)) {
+            cost_c = (double)((wgs_c + 255) / 256) * 2 * 13 / 0.92 / 1.014;
+            if (!l.has_b) return set(32, 4, 2);     // (64-channel chunks with this tiling: 918k vs 949k step.agent/s, not built)
+        }
     }
     if (l.has_b) {
         set(32, 2, 2);
@@ -306,6 +312,7 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
             const double cost = (double)rounds * nmt / (rounds == 1 ? 0.85 : 0.92);
             if (cost < best_cost * (b_pad >= 1024 ? 0.97 : 1.0)) { best_cost = cost; best = hm; }      // near-ties: taller tile from 1,024 agents
         }
+        if (cost_c <= best_cost) return set(32, 4, 2);
         g->half = best;
         return true;
     }

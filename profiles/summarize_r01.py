@@ -9,7 +9,8 @@ SRC, DST = os.path.join(ROOT, "gpurun_out", "r01"), os.path.join(ROOT, "profiles
 os.makedirs(DST, exist_ok=True)
 
 for f in ("bench_n1.json", "bench_n1_f16x2.json", "bench_n1_configs2_cfg.json", "bench_n1_configs2_cfg_guide.json",
-          "bench_n1_closed_loop.json", "bench_n2_gloo_rehearsal.json", "batch_sweep.txt"):
+          "bench_n1_closed_loop.json", "bench_n2_gloo_rehearsal.json", "batch_sweep.txt", "batch_sweep_f16x2.txt",
+          "bench_n1_configs3_shard.json", "bench_n1_closed_loop_nocontext.json"):
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, f))
 shutil.copy(os.path.join(SRC, "kstats", "bench_kernel_stats.csv"), os.path.join(DST, "kernel_stats_bench_steps1_warmup1.csv"))
@@ -44,7 +45,7 @@ def avg(kernel_sub, counter):
 
 
 out = {}
-dom = "conv_block_kernel<13, 13, 1, 5, 32, 4, 2, 1, 32, 1, 0, 0, 0>"
+dom = "conv_block_kernel<13, 13, 1, 5, 32, 4, 2, 1, 32, 1, 0, 0, 0, 0>"
 fe, wr = avg(dom, "FETCH_SIZE"), avg(dom, "WRITE_SIZE")
 if fe is not None and wr is not None:
     out = {"kernel": "void cld::" + dom + "(cld::ConvArgs)", "batch_agents": 1024,
