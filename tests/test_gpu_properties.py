@@ -48,6 +48,24 @@ def test_edge_batches_vs_oracle(eng, oracle_w, B):
     assert np.abs(eng.decode(x, cond, cs, descaled_output=True).cpu().numpy() - tr).max() <= 1e-4
 
 
+@pytest.mark.parametrize("B", [256, 520, 1030, 1536, 2100])
+def test_every_tiling_regime_vs_oracle(eng, oracle_w, B):
+    """One U-Net evaluation and one DDPM step at batch sizes that walk the launcher's tiling choices (quarter / half / full
+    height 32-column tiles, the 8-wave 64-column K-split tiling around 1,024 agents, the 64-column tiling from 2,048; ragged
+    last tile each time) against the oracle."""
+    O, w, _ = oracle_w
+    x = torch.from_numpy(synth.normal(21, f"x{B}", (B, 52, 4))) * 1.5
+    cond = torch.from_numpy(synth.make_inputs(B, 21)["cond_feat"])
+    z = torch.from_numpy(synth.normal(22, f"z{B}", (B, 52, 4)))
+    t = 58
+    with torch.no_grad():
+        ref = O.unet_forward(w, x, cond, torch.full((B,), t, dtype=torch.long)).numpy()
+        xr, mr, _ = O.ddpm_step(w, O.schedule(100), x, cond, t, z)
+    assert np.abs(eng.unet_forward(x, cond, t).cpu().numpy() - ref).max() <= 2e-5
+    xn, mean, _ = eng.ddpm_step(x, cond, t, z)
+    assert np.abs(xn.cpu().numpy() - xr.numpy()).max() <= 1e-4 and np.abs(mean.cpu().numpy() - mr.numpy()).max() <= 1e-4
+
+
 def test_agents_are_independent_and_position_invariant(eng):
     """BASELINE configs[2] size (32 x 64 = 2,048 agents): rows of a big batch equal, bit for bit, the same
     rows evaluated in a small batch at other tile positions (no cross-agent term anywhere on the path)."""
