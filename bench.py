@@ -59,6 +59,15 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare with --gpus N: launch the N ranks as a CHILD torch.distributed.run (nothing has touched the GPU yet,
+        # and a child process rather than exec keeps this safe under a profiler's preloaded runtime) and leave with its code
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29533")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
 
