@@ -286,7 +286,7 @@ def main():
 
 def pmc_traffic(B):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
-    gfx950 correction + WRITE_SIZE, profiles/pmc_quick.sh); PMC cannot be collected inside this process, so
+    gfx950 correction + WRITE_SIZE, profiles/run_r01.sh); PMC cannot be collected inside this process, so
     the number is the committed one for the same kernel and batch size, else null."""
     try:
         import glob

@@ -160,12 +160,18 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     const int pc4 = (tid % PPR) * 4;
     const int stride1 = p.c1_real;                      // == p.c2 when a second source exists (host-checked)
     const bool real = !PADC || pc4 < p.c1_real;
-    int voff[NPIECE];
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {                  // global side first: only shifts, so the loads issue early
-        const int idx = tid + NTHR * i;
+    // A thread's pieces sit NTHR / PPR rows apart, so one VGPR offset serves them all and the row step rides in the
+    // scalar offset of the load (the full-height tiles are at the 256-VGPR cap: per-piece offsets were being spilled
+    // and reloaded inside the chunk loop, ahead of the prefetch they address).  The last piece keeps a VGPR of its
+    // own: it is the only one that can fall past the tile, and the scalar offset is not part of the range check.
+    constexpr int RSTEP = NTHR / PPR;
+    const int voff0 = ((tid / PPR) * stride1 + (real ? pc4 : 0)) * 4;
+    const int pstep = RSTEP * stride1 * 4;
+    int voff_last;
+    {
+        const int idx = tid + NTHR * (NPIECE - 1);
         const int r = (idx < NPC) ? idx / PPR : tid / PPR;
-        voff[i] = (r * stride1 + (real ? pc4 : 0)) * 4;
+        voff_last = (r * stride1 + (real ? pc4 : 0)) * 4;
     }
     const size_t tile_floats = (size_t)IN_ROWS * stride1;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
@@ -178,12 +184,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         if (cv < p.c1_pad) {                            // wave-uniform: which source feeds the chunk
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
-                const v4f v = buf_load16(rs1, voff[i], PADC ? 0 : cv * 4);
+                const v4f v = (i == NPIECE - 1) ? buf_load16(rs1, voff_last, PADC ? 0 : cv * 4)
+                                                : buf_load16(rs1, voff0, (PADC ? 0 : cv * 4) + i * pstep);
                 st[i] = real ? v : v4f{0.f, 0.f, 0.f, 0.f};
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NPIECE; ++i) st[i] = buf_load16(rs2, voff[i], (cv - p.c1_pad) * 4);
+            for (int i = 0; i < NPIECE; ++i)
+                st[i] = (i == NPIECE - 1) ? buf_load16(rs2, voff_last, (cv - p.c1_pad) * 4)
+                                          : buf_load16(rs2, voff0, (cv - p.c1_pad) * 4 + i * pstep);
         }
     };
 
