@@ -309,7 +309,10 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
             if (th && th[0] != '0' + hm && (th[0] == '0' || th[0] == '1' || th[0] == '2')) continue;
             const long n = wgs_b << hm, rounds = (n + 255) / 256;
             const int nmt = ((208 >> hm) + 15) / 16;
-            const double cost = (double)rounds * nmt / (rounds == 1 ? 0.85 : 0.92);
+            double cost = (double)rounds * nmt / (rounds == 1 ? 0.85 : 0.92);
+            // the full-height stride-2 tiles stage twice the rows (13 pieces per thread in flight) and still spill: measured
+            // per layer at B = 1,024 (scripts/tile_height_ab.sh) 17.7 / 14.7 / 16.1 us (26 -> 13) and 11.6 / 9.9 / 10.2 us (52 -> 26)
+            if (l.g.stride == 2 && hm == 0) cost *= 1.15;
             if (cost < best_cost * (b_pad >= 1024 ? 0.97 : 1.0)) { best_cost = cost; best = hm; }      // near-ties: taller tile from 1,024 agents
         }
         if (cost_c <= best_cost) return set(32, 4, 2);
