@@ -86,6 +86,37 @@ def test_agents_are_independent_and_position_invariant(eng):
     assert torch.equal(shuffled, big[perm])            # same tiling, other tile positions: bit-identical
 
 
+def test_max_size_batch(eng):
+    """BASELINE configs[3]'s WHOLE job on one GPU (1,024 scenes x 64 = 65,536 agents: one activation is 3.5 GB, past 32-bit
+    byte offsets): rows of the big batch equal the same rows evaluated as a 4,096-agent batch -- bit for bit through the
+    U-Net and the DDPM update (same tiling), to an ulp of the O(100 m) positions through decode + roll-out."""
+    B = 65536
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x = torch.randn(B, 52, 4, device="cuda", generator=g)
+    c = torch.randn(B, 256, device="cuda", generator=g)
+    z = torch.randn(B, 52, 4, device="cuda", generator=g)
+    cs = torch.zeros(B, 4, device="cuda"); cs[:, 2] = 5.0
+    eps = eng.unet_forward(x, c, 40)
+    xn, _, _ = eng.ddpm_step(x, c, 40, z)
+    traj = eng.decode(x, c, cs, descaled_output=True)
+    idx = torch.cat([torch.tensor([0, 1, B // 2 - 1, B // 2, B - 4097, B - 2, B - 1], device="cuda"),
+                     torch.randint(0, B, (4089,), device="cuda", generator=g)])
+    xs, cc, zs, css = x[idx].contiguous(), c[idx].contiguous(), z[idx].contiguous(), cs[idx].contiguous()
+    assert torch.isfinite(eps).all() and torch.isfinite(traj).all()
+    assert torch.equal(eps[idx], eng.unet_forward(xs, cc, 40))
+    assert torch.equal(xn[idx], eng.ddpm_step(xs, cc, 40, zs)[0])
+    assert float((traj[idx] - eng.decode(xs, cc, css, descaled_output=True)).abs().max()) <= 5e-5
+    del x, z, eps, xn, traj
+    # the full 100-step chain with explicit noise: a 5.4 GB [100, B, 52, 4] tensor walked with 64-bit offsets
+    xT = torch.randn(B, 52, 4, device="cuda", generator=g)
+    nz = torch.randn(100, B, 52, 4, device="cuda", generator=g)
+    x0, x1, lp = eng.sample(xT, c, noise=nz)
+    x0s, x1s, lps = eng.sample(xT[idx].contiguous(), cc, noise=nz[:, idx].contiguous())
+    assert torch.equal(x0[idx], x0s) and torch.equal(x1[idx], x1s) and torch.equal(lp[idx], lps)
+    del xT, nz, x0, x1, lp, c
+    torch.cuda.empty_cache()
+
+
 def test_full_size_chain_properties(eng):
     """configs[1] size (1,024 agents, 100 steps): finite, deterministic, log_prob_final is the closed form,
     and a 24-agent prefix run alone gives the same trajectories to chain-amplified rounding."""
