@@ -83,24 +83,38 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
         const int bufi = i / (PRW * 6), r = (i / 6) % PRW, c = i % 6;
         lds[bufi * BUF + r * RS + (c < 3 ? c : 224 + c)] = 0.f;
     }
-    v4f st[NPIECE];
-    auto load_plane = [&](int c) {
+    // Planes are fetched PD at a time into registers: on the structured raster 31 of 34 planes contribute no MFMAs, so a
+    // plane step is one exposed load latency (~1.3 us) + LDS store + barrier, and the compiler drains every outstanding
+    // load at each use (s_waitcnt vmcnt(0)), which turns a rolling prefetch back into a distance-1 one.  A batch exposes
+    // the latency once per PD planes.
+#ifndef CLD_STEM_PD
+#define CLD_STEM_PD 4
+#endif
+    constexpr int PD = CLD_STEM_PD;
+    static_assert(PD % 2 == 0, "the LDS image of plane c is c & 1");
+    v4f st[PD][NPIECE];
+    auto load_group = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) st[i] = cbuf_load16(rsx, voff[i], c * (HIN * HIN * 4));
+        for (int k = 0; k < PD; ++k)
+            if (c0 + k < CIN) {
+#pragma unroll
+                for (int i = 0; i < NPIECE; ++i) st[k][i] = cbuf_load16(rsx, voff[i], (c0 + k) * (HIN * HIN * 4));
+            }
     };
     // The history planes of the raster are almost empty (one +1 pixel for the agent and a -1 per neighbour,
     // trajdata_utils.py:123-156): a 16-column output block whose input window of this plane is all zeros receives exactly
     // nothing from it, so its 26 MFMAs per wave are skipped; plane_nz[c] is the 7-bit mask of blocks that do see a
     // non-zero value.  Exact for any input (a zero window contributes +-0 to every sum); dense rasters keep the full loop.
-    auto store_plane = [&](int bufi, int c) {
+    auto store_plane = [&](int bufi, int c, int slot) {
         int mk = 0;
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) {
-            const bool nz = (st[i][0] != 0.f) | (st[i][1] != 0.f) | (st[i][2] != 0.f) | (st[i][3] != 0.f);
+            const v4f v = st[slot][i];
+            const bool nz = (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
             mk |= nz ? pmask[i] : 0;
             if (soff[i] >= 0) {
                 float* d = lds + bufi * BUF + soff[i];
-                d[0] = st[i][0]; d[1] = st[i][1]; d[2] = st[i][2]; d[3] = st[i][3];
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
             }
         }
         int wm = 0;
@@ -124,18 +138,19 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     for (int m = 0; m < SMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
 
     if (tid < CIN) plane_nz[tid] = 0;
-    load_plane(0);
+    load_group(0);
     __syncthreads();
-    store_plane(0, 0);
+    store_plane(0, 0, 0);
     __syncthreads();
 
     const char* ldsb = reinterpret_cast<const char*>(lds);
-    for (int c0 = 0; c0 < CIN; c0 += 2) {
+    for (int c0 = 0; c0 < CIN; c0 += PD) {
 #pragma unroll
-        for (int cu = 0; cu < 2; ++cu) {
-            const int c = c0 + cu;
+        for (int cr = 0; cr < PD; ++cr) {
+            const int c = c0 + cr;
+            if (c >= CIN) break;
+            const int cu = cr & 1;
             const bool more = c + 1 < CIN;
-            if (more) load_plane(c + 1);
             const int blocks = __builtin_amdgcn_readfirstlane(plane_nz[c]);
             if (blocks) {
                 v4f bq[4];
@@ -181,7 +196,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
                     }
                 }
             }
-            if (more) store_plane(cu ^ 1, c + 1);
+            if (more) {
+                if (cr == PD - 1) load_group(c + 1);    // every slot has been stored: fetch the next PD planes in one batch
+                store_plane(cu ^ 1, c + 1, (cr + 1) % PD);
+            }
             __syncthreads();
         }
     }
