@@ -30,6 +30,8 @@ class CldConfig(C.Structure):
 
 PRECISIONS = {"f32": 0, "f16x2": 1}
 OPTIMIZERS = {"adam": 0, "sgd": 1}
+KERNELS = {"guide": 0, "decode": 1, "encode": 2}        # cld_debug_force_kernel
+FORMS = {"auto": 0, "valu": 1, "mfma": 2}
 
 
 class CldGuidance(C.Structure):
@@ -79,6 +81,7 @@ SIGNATURES = {
     "cld_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cld_set_stride": (C.c_int, [_P, C.c_int32]),
     "cld_debug_lds_floor": (C.c_int, [_P, C.c_size_t]),
+    "cld_debug_force_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "cld_debug_stamps": (C.c_int, [_P, _P, C.c_int32]),
     "cld_get_precision": (C.c_int, [_P]),
     "cld_version": (C.c_char_p, []),

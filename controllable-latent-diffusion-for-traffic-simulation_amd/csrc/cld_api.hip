@@ -48,7 +48,8 @@ const char* const kResnet = "context_encoder.map_encoder.encoder_heads.map_model
 struct cld_handle_s {
     cld_config cfg{};
     int stride = 1;                                  // DmModel.stride (dm_model.py:25,119): the loop visits i = ..., 2 stride, stride, 0
-    int precision = CLD_PRECISION_F32;               // cfg.precision, possibly overridden by CLD_PRECISION (experiments)
+    int precision = CLD_PRECISION_F32;               // cfg.precision
+    int force_kernel[3] = {0, 0, 0};                 // cld_debug_force_kernel: formulation of the guide / decode / encode kernels (0 = by batch size)
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
     std::map<std::string, size_t> expect;            // name -> numel
@@ -269,7 +270,11 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     auto set = [&](int kc, int nwn, int ks) { g->kc = kc; g->nwn = nwn; g->ks = ks; return true; };
     if (l.g.ain == 1)      // split-precision loop: 64-column tiling only (no K split); 64-channel chunks where the images fit
         return l.has_a ? set(l.g.stride == 2 ? 32 : 64, 4, 1) : false;
-    static const char* force = getenv("CLD_TILING");            // experiments only: A / B
+#ifdef CLD_EXPERIMENTS      // -DCLD_EXPERIMENTS builds only (A/B scripts under scripts/): the shipped library reads no environment variable
+    static const char* force = getenv("CLD_TILING");            // A / B / C
+#else
+    constexpr const char* force = nullptr;
+#endif
     if (force && force[0] == 'C' && l.c_out == 256 && l.g.ntaps == 5 && l.g.stride == 1) return set(32, 4, 2);   // 8 waves: 64 columns x 2-way K split
     if (force && force[0] == 'A' && l.has_a) return set(32, 4, 1);
     if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
@@ -283,7 +288,11 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     {
         ConvGeom c = l.g; c.kc = 32; c.nwn = 4; c.ks = 2;
         const long wgs_c = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64);
-        static const char* tc = getenv("CLD_TILING_C");       // experiments: "0" = never, "all" = every layer shape that has an instance
+#ifdef CLD_EXPERIMENTS
+        static const char* tc = getenv("CLD_TILING_C");       // "0" = never, "all" = every layer shape that has an instance
+#else
+        constexpr const char* tc = nullptr;
+#endif
         const bool widest_only = !(tc && tc[0] == 'a');
         if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c)) {
             cost_c = (double)((wgs_c + 255) / 256) * 2 * 13 / 0.92 / 1.014;
@@ -299,7 +308,11 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
         // to the taller tile from 1,024 agents (narrow layers there: 945k vs 935k step.agent/s) and to the shorter one below
         // (B = 512: 817k vs 795k).  Sample latency 74 -> 31 ms at B <= 128;
         // throughput x2.4 at B = 64 (208k), x1.9 at 256 (650k), x1.2 at 512 (817k), x1.14 at 768.
-        static const char* th = getenv("CLD_TILING_HALF");        // experiments: "0" full tiles only, "1" / "2" force that height
+#ifdef CLD_EXPERIMENTS
+        static const char* th = getenv("CLD_TILING_HALF");        // "0" full tiles only, "1" / "2" force that height
+#else
+        constexpr const char* th = nullptr;
+#endif
         const long wgs_b = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 32);
         int best = 0;
         double best_cost = 1e30;
@@ -382,8 +395,10 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
                     int b_pad, hipStream_t s) {
     ConvGeom ga, gb;
     if (!pick_tiling(la, b_pad, &ga) || !pick_tiling(lb, b_pad, &gb)) return hipErrorInvalidValue;
-    static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;   // diagnostics
+#ifdef CLD_EXPERIMENTS      // diagnostics (tests/tools/debug_split.py): stop a U-Net evaluation after N launches
+    static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;
     if (h->launch_counter >= stop_after) return hipSuccess;
+#endif
     h->launch_counter += 2;
     if (ga.nwn == gb.nwn && ga.ks == gb.ks && conv_pair_supported(ga, gb)) return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
     hipError_t e = launch_maybe_timed(h, la, ga, aa, b_pad, s);
@@ -393,8 +408,10 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
 hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
                     const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
     ConvArgs a = make_args(h, l, x1, x2, y, res, cb, tb_row);
-    static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;   // diagnostics
+#ifdef CLD_EXPERIMENTS
+    static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;
     if (h->launch_counter >= stop_after) return hipSuccess;
+#endif
     a.stamps = (h->stamp_buf && h->launch_counter == h->stamp_layer) ? h->stamp_buf : nullptr;
     h->launch_counter++;
     ConvGeom g;
@@ -495,7 +512,6 @@ int cld_create(const cld_config* cfg, cld_handle* out) {
     cld_handle h = new cld_handle_s();
     h->cfg = *cfg;
     h->precision = cfg->precision;
-    if (const char* v = getenv("CLD_PRECISION")) h->precision = (v[0] == 'f' && v[1] == '1') ? CLD_PRECISION_F16X2 : CLD_PRECISION_F32;
     if (h->precision != CLD_PRECISION_F32 && h->precision != CLD_PRECISION_F16X2) { delete h; return CLD_ERR_ARG; }
     add_expect(h);
     build_schedule(h);
@@ -523,6 +539,12 @@ int cld_set_stride(cld_handle h, int32_t stride) {
 int cld_debug_lds_floor(cld_handle h, size_t bytes) {
     if (!h) return CLD_ERR_ARG;
     h->lds_floor = bytes;
+    return CLD_OK;
+}
+
+int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
+    if (!h || which < 0 || which > 2 || form < 0 || form > 2) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    h->force_kernel[which] = form;
     return CLD_OK;
 }
 
@@ -1023,7 +1045,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
             g.ext_grad = gd->ext_grad;
             g.scratch = w.guide; g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
             g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
-            HIPCK(h, launch_guide(h->dec, h->dyn, g, s));
+            HIPCK(h, launch_guide(h->dec, h->dyn, g, s, h->force_kernel[CLD_KERNEL_GUIDE]));
         }
         if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
         if (i == 0) {
@@ -1077,7 +1099,7 @@ int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const 
     g.z = z; g.mean_out = mean_guided; g.x_out = x_next; g.grad_out = grad; g.scratch = w.guide;
     g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
     g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B;
-    HIPCK(h, launch_guide(h->dec, h->dyn, g, static_cast<hipStream_t>(stream)));
+    HIPCK(h, launch_guide(h->dec, h->dyn, g, static_cast<hipStream_t>(stream), h->force_kernel[CLD_KERNEL_GUIDE]));
     return CLD_OK;
 }
 
@@ -1104,7 +1126,7 @@ int cld_lstm_decode(cld_handle h, const float* z, const float* cond, float* act,
     if (!h) return CLD_ERR_ARG;
     if (!h->finalized || !h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_lstm_decode: decoder weights not loaded");
     if (!z || !cond || !act || B < 1) return fail(h, CLD_ERR_ARG, "cld_lstm_decode: bad argument");
-    HIPCK(h, launch_decode(h->dec, h->dyn, z, cond, nullptr, act, nullptr, B, 1, static_cast<hipStream_t>(stream)));
+    HIPCK(h, launch_decode(h->dec, h->dyn, z, cond, nullptr, act, nullptr, B, 1, static_cast<hipStream_t>(stream), h->force_kernel[CLD_KERNEL_DECODE]));
     return CLD_OK;
 }
 
@@ -1123,7 +1145,7 @@ int cld_decode(cld_handle h, const float* z, const float* cond, const float* cur
     if (!h->finalized || !h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_decode: decoder weights not loaded");
     if (!z || !cond || !curr_states || !traj || B < 1) return fail(h, CLD_ERR_ARG, "cld_decode: bad argument");
     HIPCK(h, launch_decode(h->dec, h->dyn, z, cond, curr_states, act_out, traj, B, descaled_output,
-                           static_cast<hipStream_t>(stream)));
+                           static_cast<hipStream_t>(stream), h->force_kernel[CLD_KERNEL_DECODE]));
     return CLD_OK;
 }
 
@@ -1132,7 +1154,7 @@ int cld_traj2z(cld_handle h, const float* x6_scaled, const float* cond, const fl
     if (!h) return CLD_ERR_ARG;
     if (!h->finalized || !h->has_encoder) return fail(h, CLD_ERR_STATE, "cld_traj2z: encoder weights not loaded");
     if (!x6_scaled || !cond || B < 1 || (!z && !mu && !logvar)) return fail(h, CLD_ERR_ARG, "cld_traj2z: bad argument");
-    HIPCK(h, launch_encode(h->enc, x6_scaled, cond, noise, z, mu, logvar, B, static_cast<hipStream_t>(stream)));
+    HIPCK(h, launch_encode(h->enc, x6_scaled, cond, noise, z, mu, logvar, B, static_cast<hipStream_t>(stream), h->force_kernel[CLD_KERNEL_ENCODE]));
     return CLD_OK;
 }
 

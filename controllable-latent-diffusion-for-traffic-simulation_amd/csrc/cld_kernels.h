@@ -123,9 +123,12 @@ struct DynParams {
     float dt, acc_lo, acc_hi, v_lo, v_hi, max_steer, max_yawvel;
     float mean[6], std[6];
 };
+// Kernel formulation of the three recurrent kernels (decode / encode / guide): picked by batch size unless a test forces one
+// through cld_debug_force_kernel.
+enum { FORM_AUTO = 0, FORM_VALU = 1, FORM_MFMA = 2 };
 // z [B,52,4], cond [B,256] -> act [B,52,2] (optional) ; if cs != null also traj [B,52,6]
 hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond,
-                         const float* cs, float* act, float* traj, int B, int descaled_output, hipStream_t s);
+                         const float* cs, float* act, float* traj, int B, int descaled_output, hipStream_t s, int form = FORM_AUTO);
 hipError_t launch_action_to_state(const DynParams& d, const float* act, const float* cs, float* traj,
                                   int B, int scaled_input, int descaled_output, hipStream_t s);
 
@@ -140,7 +143,7 @@ struct EncoderWeights {   // device pointers, reference layouts
 };
 // x6 [B,52,6] (scaled state+action), cond [B,256], noise [B,52,4] or null -> z, mu, logvar [B,52,4] (any may be null)
 hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* cond, const float* noise,
-                         float* z, float* mu, float* logvar, int B, hipStream_t s);
+                         float* z, float* mu, float* logvar, int B, hipStream_t s, int form = FORM_AUTO);
 // positions [B,52,2], yaws [B,52,1], curr_speed [B] -> [B,52,6] = (x, y, v, yaw, acc, yaw-rate), optionally scaled
 hipError_t launch_state_to_state_action(const DynParams& d, const float* pos, const float* yaw, const float* speed,
                                         float* out6, int B, int scaled_output, hipStream_t s);
@@ -201,7 +204,7 @@ struct GuideArgs {
     unsigned long long seed, step_salt;
 };
 size_t guide_scratch_floats(int B);
-hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s);
+hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form = FORM_AUTO);
 
 // PPO reward (models/rl/criticmodel.py:7-64)
 struct RewardArgs {

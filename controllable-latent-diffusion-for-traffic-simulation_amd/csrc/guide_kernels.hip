@@ -750,11 +750,10 @@ static int guide_mfma_grid(int B) {
     return groups < 256 ? groups : 256;
 }
 // The MFMA kernel needs >= 16 agents per workgroup to pay off and one workgroup per CU to fill the chip: from 512 agents
-// (32 workgroups) up it is faster than the 2-agent VALU kernel (CLD_GUIDE_KERNEL=valu|mfma overrides, experiments only).
-static bool use_mfma_guide(int B) {
-    const char* force = getenv("CLD_GUIDE_KERNEL");
-    if (force && force[0] == 'v') return false;
-    if (force && force[0] == 'm') return true;
+// (32 workgroups) up it is faster than the 2-agent VALU kernel (tests force either form through cld_debug_force_kernel).
+static bool use_mfma_guide(int B, int form) {
+    if (form == FORM_VALU) return false;
+    if (form == FORM_MFMA) return true;
     return B >= 512;
 }
 size_t guide_scratch_floats(int B) {
@@ -763,8 +762,8 @@ size_t guide_scratch_floats(int B) {
     return valu > mfma ? valu : mfma;
 }
 
-hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s) {
-    if (use_mfma_guide(a.B)) hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a);
+hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
+    if (use_mfma_guide(a.B, form)) hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a);
     else hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
     return hipGetLastError();
 }

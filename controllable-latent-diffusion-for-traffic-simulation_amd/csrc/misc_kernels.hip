@@ -534,11 +534,10 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const DecoderWeights w
 }
 
 hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond, const float* cs,
-                         float* act, float* traj, int B, int descaled_output, hipStream_t s) {
+                         float* act, float* traj, int B, int descaled_output, hipStream_t s, int form) {
     // from 256 agents (16 workgroups of 16) the MFMA kernel is faster than one VALU workgroup per agent
-    // (CLD_DECODE_KERNEL=valu|mfma overrides, experiments only)
-    const char* force = getenv("CLD_DECODE_KERNEL");
-    const bool mfma = force ? force[0] == 'm' : B >= 256;
+    // (tests force either form through cld_debug_force_kernel)
+    const bool mfma = form != FORM_AUTO ? form == FORM_MFMA : B >= 256;
     if (mfma) {
         const int groups = (B + 15) / 16;
         hipLaunchKernelGGL(decode_mfma_kernel, dim3(groups < 1024 ? groups : 1024), dim3(256), 0, s, w, d, z, cond, cs, act,
@@ -809,9 +808,8 @@ __global__ __launch_bounds__(256) void encode_mfma_kernel(const EncoderWeights w
 }
 
 hipError_t launch_encode(const EncoderWeights& w, const float* x6, const float* cond, const float* noise, float* z,
-                         float* mu, float* logvar, int B, hipStream_t s) {
-    const char* force = getenv("CLD_ENCODE_KERNEL");      // experiments only: valu | mfma
-    const bool mfma = force ? force[0] == 'm' : B >= 256;
+                         float* mu, float* logvar, int B, hipStream_t s, int form) {
+    const bool mfma = form != FORM_AUTO ? form == FORM_MFMA : B >= 256;
     if (mfma) {
         const int groups = (B + 15) / 16;
         hipLaunchKernelGGL(encode_mfma_kernel, dim3(groups < 1024 ? groups : 1024), dim3(256), 0, s, w, x6, cond, noise, z, mu,

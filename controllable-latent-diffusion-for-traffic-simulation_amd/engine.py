@@ -103,6 +103,13 @@ class Engine:
         self._check(self.lib.cld_set_stride(self._h, int(stride)), "cld_set_stride")
         self.stride = int(stride)
 
+    def force_kernel(self, which: str, form: str = "auto"):
+        """Tests only (cld_debug_force_kernel): run the "guide" / "decode" / "encode" kernel of this engine in its "valu" or
+        "mfma" formulation instead of letting the batch size pick ("auto")."""
+        if which not in _lib.KERNELS or form not in _lib.FORMS:
+            raise CldError(f"force_kernel: unknown kernel '{which}' or formulation '{form}'")
+        self._check(self.lib.cld_debug_force_kernel(self._h, _lib.KERNELS[which], _lib.FORMS[form]), "cld_debug_force_kernel")
+
     @property
     def loop_steps(self) -> int:
         return len(range(0, self.n_timesteps, self.stride))

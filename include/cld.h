@@ -314,6 +314,17 @@ int cld_debug_stamps(cld_handle h, void* buf /*DEVICE, u64[16 * workgroups]*/, i
  * workgroups of which stream can share a CU when two handles run on two streams (scripts/exp_streams.py). */
 int cld_debug_lds_floor(cld_handle h, size_t bytes);
 
+/* Tests only: force the formulation of one of the three recurrent kernels of this handle instead of letting the batch size
+ * pick it (both forms compute the same function; the parity tests run each against the oracle).  The shipped library reads
+ * no environment variable: every behaviour switch is an explicit call like this one. */
+#define CLD_KERNEL_GUIDE 0    /* guidance: LSTM forward + BPTT + roll-out backward (cld_sample_guided, cld_guidance_step) */
+#define CLD_KERNEL_DECODE 1   /* cld_lstm_decode, cld_decode */
+#define CLD_KERNEL_ENCODE 2   /* cld_traj2z */
+#define CLD_FORM_AUTO 0       /* by batch size (default) */
+#define CLD_FORM_VALU 1       /* one or two agents per workgroup, gate rows in registers */
+#define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 MFMA tiles */
+int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);
+
 /* CLD_PRECISION_* the handle runs with. */
 int cld_get_precision(cld_handle h);
 

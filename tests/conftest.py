@@ -23,6 +23,16 @@ def load_golden(name):
     return meta, arrays
 
 
+# Every GPU test module runs once per arithmetic mode of the library (include/cld.h CLD_PRECISION_*): the exact-fp32 MFMA
+# default and the optional f16x2 split mode, same parity bars.  CLD_TEST_PRECISION=f32|f16x2 narrows a run to one mode.
+_PRECISIONS = [os.environ["CLD_TEST_PRECISION"]] if os.environ.get("CLD_TEST_PRECISION") else ["f32", "f16x2"]
+
+
+@pytest.fixture(scope="module", params=_PRECISIONS)
+def precision(request):
+    return request.param
+
+
 @pytest.fixture(scope="session")
 def golden():
     return load_golden

@@ -16,7 +16,15 @@ NBUF_OFF = 3 * 208 + 1792          # floats per agent before the activation buff
 ACT = 3328
 
 
-PRECISION = __import__("os").environ.get("CLD_TEST_PRECISION", "f32")     # the whole file runs per precision mode
+PRECISION = "f32"     # set per module run by the `precision` fixture (tests/conftest.py): the whole file runs per precision mode
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _precision_mode(precision):
+    global PRECISION
+    PRECISION = precision
+    yield
+    PRECISION = "f32"
 
 
 def _engine(n=100, jitter=True, decoder=True):
@@ -29,12 +37,12 @@ def _engine(n=100, jitter=True, decoder=True):
 
 
 @pytest.fixture(scope="module")
-def eng_jitter():
+def eng_jitter(_precision_mode):
     return _engine(100, True)
 
 
 @pytest.fixture(scope="module")
-def eng_default():
+def eng_default(_precision_mode):
     return _engine(100, False)
 
 
@@ -212,7 +220,7 @@ def test_encoder_row_golden(golden):
 # f-1  ContextEncoder (models/context_utils.py:8-61)
 # ---------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
-def eng_ctx():
+def eng_ctx(_precision_mode):
     from cld_amd.engine import Engine
     e = Engine(n_timesteps=10, device="cuda:0")
     e.load_state_dict(synth.make_unet_weights(0))
@@ -300,7 +308,7 @@ def test_guidance_step_golden(golden, eng_jitter, opt):
 
 
 @pytest.fixture(scope="module")
-def eng10():
+def eng10(_precision_mode):
     return _engine(10, True)
 
 
@@ -391,12 +399,12 @@ def test_guidance_mfma_kernel_vs_oracle_and_valu(eng_jitter):
     gd = {"curr_states": cs, "target_speed": tgt, "lr": 2.0, "perturb_th": None, "optimizer": "sgd"}
     outs = {}
     for k in ("mfma", "valu"):
-        os.environ["CLD_GUIDE_KERNEL"] = k
+        eng_jitter.force_kernel("guide", k)
         try:
             outs[k] = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
             torch.cuda.synchronize()
         finally:
-            del os.environ["CLD_GUIDE_KERNEL"]
+            eng_jitter.force_kernel("guide", "auto")
     torch.set_num_threads(8)
     _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, tgt, None, 2.0, None, "sgd")
     gmax = gref.abs().max().item()
@@ -451,12 +459,12 @@ def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
     al = torch.tensor([c["scene0"]["acc_limit"][1] / (n0 * 52)] * n0 + [0.0] * n1)
     gd = {"curr_states": cs, "target_speed": tgt, "loss_scale": ts, "speed_limit": (c["scene0"]["speed_limit"][0], sl),
           "acc_limit": (c["scene0"]["acc_limit"][0], al), "lr": c["lr"], "perturb_th": None, "optimizer": "sgd"}
-    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    eng_jitter.force_kernel("guide", kernel)
     try:
         mg = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5)
         torch.cuda.synchronize()
     finally:
-        del os.environ["CLD_GUIDE_KERNEL"]
+        eng_jitter.force_kernel("guide", "auto")
     step = np.abs(g["guided_combo_sgd"] - mean.numpy()).max()
     assert np.abs(mg.cpu().numpy() - g["guided_combo_sgd"]).max() <= max(3e-5 * step, 2.5e-7)
     # a speed limit alone (no target-speed term) is accepted too
@@ -481,12 +489,12 @@ def test_guidance_waypoint_golden(golden, eng_jitter, kernel):
     ts = torch.tensor([0.0] * n0 + [c["scene1_target_speed_weight"] / (n1 * 52)] * n1)
     gd = {"curr_states": cs, "target_speed": tgt, "loss_scale": ts, "target_pos": (wp, wt, tps), "lr": c["lr"], "perturb_th": None,
           "optimizer": "sgd"}
-    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    eng_jitter.force_kernel("guide", kernel)
     try:
         mg, grad = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
         torch.cuda.synchronize()
     finally:
-        del os.environ["CLD_GUIDE_KERNEL"]
+        eng_jitter.force_kernel("guide", "auto")
     _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, tgt, ts, c["lr"], None, "sgd", target_pos=(wp, wt, tps))
     assert (grad.cpu() - gref).abs().max().item() <= 5e-5 * gref.abs().max().item()
     step = np.abs(g["guided_waypoint_sgd"] - mean.numpy()).max()
@@ -515,7 +523,7 @@ def test_guidance_waypoint_yaw_bound_path(kernel):
     wt = torch.from_numpy(synth.uniform(31, "wt", (B,), 5.0, 51.9)).long()
     tps = torch.full((B,), 1.0 / B)
     gd = {"curr_states": cs, "target_pos": (wp, wt, tps), "lr": 1.0, "perturb_th": None, "optimizer": "sgd"}
-    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    e.force_kernel("guide", kernel)
     old = O.NORM_STD
     try:
         _, grad = e.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
@@ -530,7 +538,7 @@ def test_guidance_waypoint_yaw_bound_path(kernel):
             clipped = (traj[..., 5].abs() > yb).float().mean().item()
     finally:
         O.NORM_STD = old
-        del os.environ["CLD_GUIDE_KERNEL"]
+        e.force_kernel("guide", "auto")
     assert clipped > 0.05, clipped
     assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
 
@@ -549,12 +557,12 @@ def test_guidance_targetpos_softmin_golden(golden, eng_jitter, kernel):
     wt = torch.tensor([-(m + 1)] * n0 + [0] * n1)
     tps = torch.tensor([c["weight"] / n0] * n0 + [0.0] * n1)
     gd = {"curr_states": cs, "target_pos": (wp, wt, tps), "lr": c["lr"], "perturb_th": None, "optimizer": "sgd"}
-    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    eng_jitter.force_kernel("guide", kernel)
     try:
         mg, grad = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
         torch.cuda.synchronize()
     finally:
-        del os.environ["CLD_GUIDE_KERNEL"]
+        eng_jitter.force_kernel("guide", "auto")
     _, gref = O.guidance_step(O.to_torch(synth.make_decoder_weights(0)), mean, cond, cs, None, None, c["lr"], None, "sgd", target_pos=(wp, wt, tps))
     assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
     step = np.abs(g["guided_targetpos_sgd"] - mean.numpy()).max()
@@ -630,7 +638,7 @@ def test_decode_vjp_vs_autograd(kernel):
     cs[:, 2] = torch.from_numpy(synth.uniform(41, "slow", (B,), 0.05, 8.0))
     z = torch.from_numpy(synth.normal(41, "z", (B, 52, 4)))
     G = torch.from_numpy(synth.normal(41, "G", (B, 52, 6)))
-    os.environ["CLD_GUIDE_KERNEL"] = kernel
+    e.force_kernel("guide", kernel)
     old = O.NORM_STD
     try:
         got = e.decode_vjp(z, cond, cs, G).cpu()
@@ -640,7 +648,7 @@ def test_decode_vjp_vs_autograd(kernel):
         (ref,) = torch.autograd.grad((traj * G).sum(), zz)
     finally:
         O.NORM_STD = old
-        del os.environ["CLD_GUIDE_KERNEL"]
+        e.force_kernel("guide", "auto")
     assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
@@ -771,12 +779,12 @@ def test_decode_mfma_kernel_vs_oracle_and_valu(eng_jitter):
     z = torch.from_numpy(synth.normal(51, "z", (B, 52, 4)))
     outs = {}
     for k in ("mfma", "valu"):
-        os.environ["CLD_DECODE_KERNEL"] = k
+        eng_jitter.force_kernel("decode", k)
         try:
             outs[k] = eng_jitter.decode(z, cond, cs, descaled_output=True, want_act=True)
             torch.cuda.synchronize()
         finally:
-            del os.environ["CLD_DECODE_KERNEL"]
+            eng_jitter.force_kernel("decode", "auto")
     wd = O.to_torch(synth.make_decoder_weights(0))
     torch.set_num_threads(8)
     act_ref = O.lstm_decode(wd, z, cond)
@@ -804,12 +812,12 @@ def test_encode_mfma_kernel_vs_oracle_and_valu():
     nz = torch.from_numpy(synth.normal(61, "nz", (B, 52, 4)))
     outs = {}
     for k in ("mfma", "valu"):
-        os.environ["CLD_ENCODE_KERNEL"] = k
+        e.force_kernel("encode", k)
         try:
             outs[k] = e.traj2z(x6, cond, nz)
             torch.cuda.synchronize()
         finally:
-            del os.environ["CLD_ENCODE_KERNEL"]
+            e.force_kernel("encode", "auto")
     torch.set_num_threads(8)
     ref = O.traj2z(O.to_torch(synth.make_encoder_weights(0)), x6, cond, nz)
     for k in ("mfma", "valu"):

@@ -15,10 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def eng():
-    import os
+def eng(precision):
     from cld_amd.engine import Engine
-    e = Engine(n_timesteps=100, device="cuda:0", precision=os.environ.get("CLD_TEST_PRECISION", "f32"))
+    e = Engine(n_timesteps=100, device="cuda:0", precision=precision)
     e.load_state_dict(synth.make_unet_weights(0, affine_jitter=True))
     e.load_state_dict(synth.make_decoder_weights(0))
     return e.finalize()

@@ -32,7 +32,7 @@ p = "model.downs.0.0"
 R0 = F.conv1d(h, w[p + ".residual_conv.weight"], w[p + ".residual_conv.bias"])
 H0 = O.conv_block(h, w, p + ".blocks.0") + F.linear(F.mish(tc), w[p + ".time_mlp.1.weight"], w[p + ".time_mlp.1.bias"])[:, :, None]
 A0 = O.conv_block(H0, w, p + ".blocks.1") + R0
-stop = int(os.environ.get("CLD_DEBUG_STOP", "99"))
+stop = int(os.environ.get("CLD_DEBUG_STOP", "99"))      # honoured by -DCLD_EXPERIMENTS builds only (select one with CLD_LIB_PATH)
 print("stop", stop)
 print("R0 (b0) err", float((buf(0, 64, 52, s22) - R0).abs().max()))
 if stop == 2: print("H0 (b1) err", float((buf(1, 64, 52, s22) - H0).abs().max()))
