@@ -41,7 +41,9 @@ class CldGuidance(C.Structure):
                 ("speed_limit", C.c_float), ("acc_limit", C.c_float),
                 ("speed_limit_scale", C.c_void_p), ("acc_limit_scale", C.c_void_p),
                 ("target_pos", C.c_void_p), ("target_time", C.c_void_p), ("target_pos_scale", C.c_void_p),
-                ("ext_grad", C.c_void_p)]
+                ("ext_grad", C.c_void_p),
+                ("apply_output", C.c_int32), ("no_intermediate", C.c_int32),
+                ("final_lr", C.c_float), ("final_perturb_th", C.c_float), ("final_optimizer", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -64,6 +66,7 @@ SIGNATURES = {
     "cld_sample_guided": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.POINTER(CldGuidance), C.c_int32, _P, _P, _P, C.c_int32,
                                     C.c_uint64, _P, C.c_size_t, _P]),
     "cld_guidance_step": (C.c_int, [_P, _P, _P, C.POINTER(CldGuidance), C.c_float, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P]),
+    "cld_guidance_losses": (C.c_int, [_P, _P, C.POINTER(CldGuidance), _P, C.c_int32, _P]),
     "cld_log_prob": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_lstm_decode": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P]),
     "cld_action_to_state": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -53,7 +53,7 @@ struct cld_handle_s {
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
     std::map<std::string, size_t> expect;            // name -> numel
-    bool finalized = false, has_decoder = false;
+    bool finalized = false, has_decoder = false, has_unet = false;
     std::vector<void*> dev_allocs;
     // schedule (host, fp32 as in dm_model.py:29-56)
     std::vector<float> x_t_cof, noise_cof, plvc, sqrt_acp, sqrt_1m_acp;
@@ -609,13 +609,22 @@ int cld_finalize(cld_handle h, void* stream) {
     if (!h) return CLD_ERR_ARG;
     if (h->finalized) return fail(h, CLD_ERR_STATE, "cld_finalize: already finalized");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // The U-Net is optional as a whole (a VAE-only or ContextEncoder-only handle is legal: VaeModel without a DmModel), never in part
+    size_t unet_have = 0, unet_want = 0;
+    std::string unet_missing;
     for (const auto& kv : h->expect)
-        if (kv.first.rfind("model.", 0) == 0 && !h->w.count(kv.first))
-            return fail(h, CLD_ERR_STATE, "cld_finalize: missing weight '" + kv.first + "'");
+        if (kv.first.rfind("model.", 0) == 0) {
+            ++unet_want;
+            if (h->w.count(kv.first)) ++unet_have;
+            else if (unet_missing.empty()) unet_missing = kv.first;
+        }
+    if (unet_have != 0 && unet_have != unet_want) return fail(h, CLD_ERR_STATE, "cld_finalize: missing weight '" + unet_missing + "'");
+    h->has_unet = unet_have == unet_want;
     hipError_t e = hipSuccess;
 #define UP(dst, vec) do { dst = upload(h, vec, s, &e); if (e != hipSuccess) return fail(h, CLD_ERR_HIP, std::string("upload: ") + hipGetErrorString(e)); } while (0)
 
     // ---- conv layers -------------------------------------------------------------------
+    auto build_unet = [&]() -> int {
     auto make_conv = [&](ConvLayer& l, const std::string& wname, int c_out, int c1_real, int c2, int L_in, int lm,
                          int stride, int ntaps, const int* tapk, bool transposed, int off0, int orow0, int ostr,
                          int ly, int epi, const std::string& gn_name, bool in_f32 = false, bool out_f32 = false) -> int {
@@ -745,6 +754,13 @@ int cld_finalize(cld_handle h, void* stream) {
     }
     UP(h->head_w, *getw(h, "model.final_conv.1.weight"));
     UP(h->head_b, *getw(h, "model.final_conv.1.bias"));
+    return CLD_OK;
+    };
+    if (h->has_unet) {
+        const int rcu = build_unet();
+        if (rcu != CLD_OK) return rcu;
+    }
+    int rc = CLD_OK;
 
     // ---- decoder (optional) ---------------------------------------------------------------
     h->has_decoder = true;
@@ -901,6 +917,7 @@ int cld_get_schedule(cld_handle h, float* x_t_cof, float* noise_cof, float* post
 static int check_common(cld_handle h, const char* fn, int B, int t_idx, const void* ws, size_t ws_bytes) {
     if (!h) return CLD_ERR_ARG;
     if (!h->finalized) return fail(h, CLD_ERR_STATE, std::string(fn) + ": weights not finalized");
+    if (!h->has_unet && std::string(fn) != "cld_guidance_step") return fail(h, CLD_ERR_STATE, std::string(fn) + ": U-Net weights (model.*) not loaded");
     if (B < 1) return fail(h, CLD_ERR_ARG, std::string(fn) + ": B < 1");
     if (t_idx < 0 || t_idx >= h->cfg.n_timesteps) return fail(h, CLD_ERR_ARG, std::string(fn) + ": timestep out of range");
     if (!ws || ws_bytes < cld_workspace_bytes(h, B)) return fail(h, CLD_ERR_WORKSPACE, std::string(fn) + ": workspace too small");
@@ -947,12 +964,13 @@ int cld_denoise_loss(cld_handle h, const float* z0, const float* noise, const fl
                      float* mse, int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_common(h, "cld_denoise_loss", B, 0, workspace, workspace_bytes);
     if (rc) return rc;
-    if (!z0 || !noise || !cond || !t_idx || !mse) return fail(h, CLD_ERR_ARG, "cld_denoise_loss: null pointer");
+    if (!z0 || !noise || !t_idx || (!mse && !z_noisy) || (mse && !cond)) return fail(h, CLD_ERR_ARG, "cld_denoise_loss: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int bp = pad16(B);
     Ws w = carve(workspace, bp);
     // z_t = sqrt(acp[t]) z0 + sqrt(1 - acp[t]) noise  (q_sample, dm_model.py:91-96) straight into the padded latent buffer
     HIPCK(h, launch_q_sample(z0, noise, t_idx, h->qs_tab, h->cfg.n_timesteps, w.xw, z_noisy, B, bp, s));
+    if (!mse) return CLD_OK;               // q_sample alone (dm_model.py:91-96): no U-Net evaluation
     HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
     HIPCK(h, launch_add_time_bias(w.cb, h->tb, t_idx, h->cfg.n_timesteps, B, NCB, s));
     HIPCK(h, run_unet(h, w, w.xw, -1, bp, s));
@@ -1001,6 +1019,8 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
         if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad))
             return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
         if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
+        if (gd->apply_output && gd->final_optimizer != CLD_GUIDE_ADAM && gd->final_optimizer != CLD_GUIDE_SGD)
+            return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer for the output step");
         if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, std::string(fn) + ": target_pos_scale needs target_pos and target_time");
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1019,7 +1039,8 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
         const int i = (steps - 1 - it) * h->stride;
         HIPCK(h, run_unet(h, w, w.xw, i, bpn, s));
         const float sigma = std::exp(0.5f * h->plvc[i]);
-        const bool guide = gd && i > 0;       // upstream defaults: apply_guidance_intermediate, not apply_guidance_output
+        // upstream defaults: apply_guidance_intermediate on, apply_guidance_output off (diffuser.py:876-881, scene_edit_config.py:84-85)
+        const bool guide = gd && (i > 0 ? !gd->no_intermediate : gd->apply_output != 0);
         HeadArgs a{};
         a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
         if (cfg) { a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w; }
@@ -1043,8 +1064,10 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
             g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
             g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
             g.ext_grad = gd->ext_grad;
-            g.scratch = w.guide; g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
-            g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
+            // t = 0 (apply_guidance_output): the step's own optimiser settings, and no noise behind it (nonzero_mask, diffuser.py:929)
+            const float lr_in = i > 0 ? gd->lr : gd->final_lr, th_in = i > 0 ? gd->perturb_th : gd->final_perturb_th;
+            g.scratch = w.guide; g.lr = lr_in > 0.f ? lr_in : sigma; g.perturb_th = th_in > 0.f ? th_in : (th_in == 0.f ? sigma : -1.f);
+            g.sigma = a.sg; g.optimizer = i > 0 ? gd->optimizer : gd->final_optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
             HIPCK(h, launch_guide(h->dec, h->dyn, g, s, h->force_kernel[CLD_KERNEL_GUIDE]));
         }
         if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
@@ -1100,6 +1123,20 @@ int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const 
     g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
     g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B;
     HIPCK(h, launch_guide(h->dec, h->dyn, g, static_cast<hipStream_t>(stream), h->force_kernel[CLD_KERNEL_GUIDE]));
+    return CLD_OK;
+}
+
+int cld_guidance_losses(cld_handle h, const float* traj, const cld_guidance* gd, float* losses, int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!traj || !gd || !losses || B < 1) return fail(h, CLD_ERR_ARG, "cld_guidance_losses: bad argument");
+    if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, "cld_guidance_losses: target_pos_scale needs target_pos and target_time");
+    GuideArgs g{};
+    g.target_speed = gd->target_speed; g.loss_scale = gd->loss_scale;
+    g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
+    g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
+    g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
+    g.B = B;
+    HIPCK(h, launch_guide_losses(g, traj, losses, static_cast<hipStream_t>(stream)));
     return CLD_OK;
 }
 

@@ -206,6 +206,10 @@ struct GuideArgs {
 size_t guide_scratch_floats(int B);
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form = FORM_AUTO);
 
+// per-agent values of the built-in guidance losses on a decoded trajectory (include/cld.h cld_guidance_losses); uses the loss
+// fields of GuideArgs (target_speed, loss_scale, speed/acc limits, waypoint) and B
+hipError_t launch_guide_losses(const GuideArgs& a, const float* traj, float* losses, hipStream_t s);
+
 // PPO reward (models/rl/criticmodel.py:7-64)
 struct RewardArgs {
     const float* traj;                // [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate), agent frame

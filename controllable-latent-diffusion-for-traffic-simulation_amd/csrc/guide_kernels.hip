@@ -814,6 +814,62 @@ __global__ __launch_bounds__(64) void reward_kernel(const RewardArgs a) {
     }
 }
 
+// Values of the built-in guidance losses on decoded trajectories (upstream guide_losses, guidance_loss.py:2143-2172): one wave
+// per agent, lane t = timestep t, wave reductions.
+__global__ __launch_bounds__(64) void guide_loss_kernel(const GuideArgs a, const float* __restrict__ traj, float* __restrict__ losses) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float nan = __builtin_nanf("");
+    const bool on_ts = a.target_speed && (!a.loss_scale || a.loss_scale[b] != 0.f);
+    const bool on_sl = a.speed_limit_scale && a.speed_limit_scale[b] != 0.f;
+    const bool on_al = a.acc_limit_scale && a.acc_limit_scale[b] != 0.f;
+    const bool on_tp = a.target_pos_scale && a.target_pos_scale[b] != 0.f;
+    float ts = 0.f, sl = 0.f, al = 0.f, x = 0.f, y = 0.f;
+    if (t < 52) {
+        const float* p = traj + ((size_t)b * 52 + t) * 6;
+        x = p[0]; y = p[1];
+        const float v = p[2], acc = p[4];
+        if (on_ts) { const float d = fabsf(v - a.target_speed[(size_t)b * 52 + t]); ts = (d == d) ? d : 0.f; }     // nan_to_num(nan = 0)
+        if (on_sl) sl = fmaxf(fabsf(v) - a.speed_limit, 0.f);
+        if (on_al) al = fmaxf(fabsf(acc) - a.acc_limit, 0.f);
+    }
+    float tp = 0.f;
+    if (on_tp) {
+        const float ex = x - a.target_pos[2 * b], ey = y - a.target_pos[2 * b + 1];
+        const float dd = sqrtf(ex * ex + ey * ey);
+        int tstar = a.target_time[b];
+        if (tstar >= 0) {
+            tstar = tstar > 51 ? 51 : tstar;
+            tp = __shfl(dd, tstar);
+        } else {
+            int m = -tstar - 1;
+            m = m > 51 ? 51 : m;
+            const bool in = t >= m && t < 52;
+            float dmin = in ? dd : 3.4e38f;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) dmin = fminf(dmin, __shfl_xor(dmin, o));
+            const float e = in ? expf(-(dd - dmin)) : 0.f;
+            float z = e, S = e * dd * dd;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { z += __shfl_xor(z, o); S += __shfl_xor(S, o); }
+            tp = S / z / (float)(52 - m);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ts += __shfl_xor(ts, o); sl += __shfl_xor(sl, o); al += __shfl_xor(al, o); }
+    if (t == 0) {
+        float* o = losses + (size_t)b * 4;
+        o[0] = on_ts ? ts * (1.0f / 52.0f) : nan;
+        o[1] = on_sl ? sl * (1.0f / 52.0f) : nan;
+        o[2] = on_al ? al * (1.0f / 52.0f) : nan;
+        o[3] = on_tp ? tp : nan;
+    }
+}
+
+hipError_t launch_guide_losses(const GuideArgs& a, const float* traj, float* losses, hipStream_t s) {
+    hipLaunchKernelGGL(guide_loss_kernel, dim3(a.B), dim3(64), 0, s, a, traj, losses);
+    return hipGetLastError();
+}
+
 hipError_t launch_reward(const RewardArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(reward_kernel, dim3(a.B), dim3(64), 0, s, a);
     return hipGetLastError();

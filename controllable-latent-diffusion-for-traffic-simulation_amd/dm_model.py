@@ -7,7 +7,8 @@ x_Tminus1 / x_tminus1_mean_var / log_prob, and `.model(x, aux_info, t)` for
 callers in `src/trainers/guide_dm_trainer.py:87,164,189,207` work unchanged.
 Differences, all additive: `noise=` lets the caller supply the Gaussian draws
 (the reference draws them with `torch.randn`, which cannot be reproduced across
-devices), and training-only members (`compute_losses`, `q_sample`) are absent.
+devices); `compute_losses` / `q_sample` exist in their forward-only form (the validation loss of
+`src/trainers/dm_trainer.py:84-90`; training itself is out of scope).
 """
 from __future__ import annotations
 
@@ -40,6 +41,24 @@ def repeat_by_expand_at(x, repeats: int, dim: int = 0):
     if isinstance(x, torch.Tensor):
         return x if repeats == 1 else x.repeat_interleave(repeats, dim=dim)
     return x
+
+
+def repeat_guidance(guidance: Mapping, num_samp: int, curr_states=None) -> dict:
+    """Per-agent tensors of a `guidance=` dict follow the num_samp repeat of the batch (dm_model.py:116); `curr_states`
+    (already repeated) is filled in when the dict has none."""
+    g = dict(guidance)
+    if curr_states is not None:
+        g.setdefault("curr_states", curr_states)
+
+    def rep(v):
+        return repeat_by_expand_at(v, num_samp, 0) if isinstance(v, torch.Tensor) and v.dim() >= 1 else v
+    for k in ("target_speed", "loss_scale"):
+        if g.get(k) is not None:
+            g[k] = rep(torch.as_tensor(g[k]))
+    for k in ("speed_limit", "acc_limit", "target_pos"):
+        if g.get(k) is not None:
+            g[k] = tuple(rep(v) for v in g[k])
+    return g
 
 
 class _UnetSurface:
@@ -120,7 +139,7 @@ class DmModel:
             aux = repeat_by_expand_at(aux_info, repeats=num_samp, dim=0)
             if noise is None:
                 BN = aux["cond_feat"].shape[0]
-                noise = {"x_T": torch.randn(BN, 52, 4, device=self.device), "noise": torch.randn(self.n_timesteps, BN, 52, 4, device=self.device)}
+                noise = {"x_T": torch.randn(BN, 52, 4, device=self.device), "noise": torch.randn(self.engine.loop_steps, BN, 52, 4, device=self.device)}
             x0, x1 = self.engine.sample_with_loss(noise["x_T"], aux["cond_feat"], aux["curr_states"], noise["noise"], guidance_fn, **guidance_opt)
             return {"pred_traj": x0, "x1": x1, "log_prob_final": None, "aux_info": aux}
         return self.sample_traj(data_batch, algo_config, aux_info, noise=noise, seed=seed,
@@ -143,16 +162,12 @@ class DmModel:
             z = torch.randn(self.engine.loop_steps, BN, 52, 4, device=self.device)
         x_T = torch.as_tensor(x_T).reshape(BN, 52, 4)
         if guidance is not None:
-            guidance = dict(guidance)
-            guidance.setdefault("curr_states", aux_info["curr_states"])
-            def rep(v):                       # per-agent tensors follow the num_samp repeat of the batch (dm_model.py:116)
-                return repeat_by_expand_at(v, num_samp, 0) if isinstance(v, torch.Tensor) and v.dim() >= 1 else v
-            for k in ("target_speed", "loss_scale"):
-                if guidance.get(k) is not None:
-                    guidance[k] = rep(torch.as_tensor(guidance[k]))
-            for k in ("speed_limit", "acc_limit", "target_pos"):
-                if guidance.get(k) is not None:
-                    guidance[k] = tuple(rep(v) for v in guidance[k])
+            guidance = repeat_guidance(guidance, num_samp, aux_info["curr_states"])
+        if class_free_guide_w and aux_info.get("non_cond_feat") is None:
+            # upstream builds non_cond_feat itself (diffuser.py:390-411,459-471); here the ContextEncoder mirror does
+            # (`include_class_free_cond=True`, Engine.non_cond_feat).  Running unguided instead would be a silent wrong answer.
+            raise CldError("class_free_guide_w != 0 needs aux_info['non_cond_feat'] [B,256] (ContextEncoder(..., include_class_free_cond=True) "
+                           "or Engine.non_cond_feat(curr_states) produce it)")
         x0, x1, logp = self.engine.sample(x_T, aux_info["cond_feat"], noise=z, seed=seed,
                                           non_cond=aux_info.get("non_cond_feat") if class_free_guide_w else None,
                                           guidance_w=class_free_guide_w, guidance=guidance)
@@ -181,7 +196,7 @@ class DmModel:
 
     # ---- dm_model.py:82-96 (forward only: the validation loss of dm_trainer.py:84-90) ---------
     def q_sample(self, x_0, t, noise):
-        return self.engine.denoise_loss(x_0, noise, torch.zeros(x_0.shape[0], 256, device=self.device), t, want_z_noisy=True)[1]
+        return self.engine.q_sample(x_0, noise, t)
 
     def compute_losses(self, aux_info, z0, t=None, noise=None):
         """MSE between the drawn noise and the U-Net's prediction on q_sample(z0, t, noise); `t` / `noise` default to the

@@ -150,9 +150,7 @@ class Engine:
         x = self._f32(x)
         B = x.shape[0]
         x = self._f32(x, (B, T, D)); cond = self._f32(cond, (B, COND))
-        t = torch.as_tensor(t).reshape(-1).to(self.device, torch.int32).contiguous()
-        if t.numel() != B:
-            raise CldError(f"expected {B} timesteps, got {t.numel()}")
+        t = self._timesteps(t, B)
         eps = torch.empty_like(x)
         ws, wsn = self._workspace(B)
         with torch.cuda.device(self.device):
@@ -160,13 +158,35 @@ class Engine:
                         "cld_unet_forward_t")
         return eps
 
+    def _timesteps(self, t, B: int) -> torch.Tensor:
+        """Per-row timesteps -> int32 [B] on the device, range-checked on the host (the kernels index tables with them)."""
+        t = torch.as_tensor(t).reshape(-1).to(torch.int64)
+        if t.numel() != B:
+            raise CldError(f"expected {B} timesteps, got {t.numel()}")
+        if t.numel() and (int(t.min()) < 0 or int(t.max()) >= self.n_timesteps):
+            raise CldError(f"timestep out of range [0, {self.n_timesteps})")
+        return t.to(self.device, torch.int32).contiguous()
+
+    def q_sample(self, z0, noise, t):
+        """DmModel.q_sample (dm_model.py:91-96): sqrt(acp[t]) z0 + sqrt(1 - acp[t]) noise, per-row t."""
+        z0 = self._f32(z0)
+        B = z0.shape[0]
+        z0 = self._f32(z0, (B, T, D)); noise = self._f32(noise, (B, T, D))
+        t = self._timesteps(t, B)
+        zn = torch.empty_like(z0)
+        ws, wsn = self._workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_denoise_loss(self._h, _ptr(z0), _ptr(noise), None, _ptr(t), _ptr(zn), None, B,
+                                                  ws, wsn, self._stream()), "cld_denoise_loss")
+        return zn
+
     def denoise_loss(self, z0, noise, cond, t, want_z_noisy=False):
         """Forward half of DmModel.compute_losses (dm_model.py:82-96): per-sample MSE [B] between `noise` and the U-Net's
         prediction on q_sample(z0, t, noise); the reference's scalar loss is its mean."""
         z0 = self._f32(z0)
         B = z0.shape[0]
         z0 = self._f32(z0, (B, T, D)); noise = self._f32(noise, (B, T, D)); cond = self._f32(cond, (B, COND))
-        t = torch.as_tensor(t).reshape(-1).to(self.device, torch.int32).contiguous()
+        t = self._timesteps(t, B)
         mse = torch.empty(B, dtype=torch.float32, device=self.device)
         zn = torch.empty_like(z0) if want_z_noisy else None
         ws, wsn = self._workspace(B)
@@ -220,13 +240,39 @@ class Engine:
         opt = g.get("optimizer", "adam")
         if opt not in _lib.OPTIMIZERS:
             raise CldError(f"unknown guidance optimizer '{opt}' (adam | sgd)")
+        # guidance on the t = 0 output (upstream apply_guidance_output + final_step_opt_params, scene_edit_config.py:84-91):
+        # "output": True | dict(lr, perturb_th, optimizer); "intermediate": False switches the t > 0 steps off
+        fo = g.get("output")
+        fo = {} if fo is True else fo
+        fopt = (fo or {}).get("optimizer", "adam")
+        if fopt not in _lib.OPTIMIZERS:
+            raise CldError(f"unknown guidance optimizer '{fopt}' (adam | sgd)")
+        fth = (fo or {}).get("perturb_th", 1.0)
         cg = _lib.CldGuidance(cs.data_ptr(), None if ts is None else ts.data_ptr(), None if ls is None else ls.data_ptr(),
                               float(g["lr"]) if g.get("lr") else 0.0,
                               -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
                               sl, al, None if sls is None else sls.data_ptr(), None if als is None else als.data_ptr(),
                               None if tp is None else tp.data_ptr(), None if tt is None else tt.data_ptr(),
-                              None if tps is None else tps.data_ptr(), None if eg is None else eg.data_ptr())
+                              None if tps is None else tps.data_ptr(), None if eg is None else eg.data_ptr(),
+                              0 if fo is None or fo is False else 1, 0 if g.get("intermediate", True) else 1,
+                              float((fo or {}).get("lr", 0.3) or 0.0),
+                              -1.0 if fth is None else (0.0 if fth == "sigma" else float(fth)), _lib.OPTIMIZERS[fopt])
         return cg, (cs, ts, ls, sls, als, tp, tt, tps, eg)
+
+    def guidance_losses(self, traj, guidance: Mapping):
+        """Per-agent values of the built-in guidance losses on decoded trajectories [B,52,6] (descaled) -> [B,4] =
+        (target_speed, speed_limit, acc_limit, waypoint), NaN where a term is off for the agent: what upstream reports as
+        `guide_losses` and selects samples by (guidance_loss.py:2143-2172, algos.py:2057-2064)."""
+        traj = self._f32(traj)
+        B = traj.shape[0]
+        traj = self._f32(traj, (B, T, 6))
+        g = dict(guidance)
+        g.setdefault("curr_states", torch.zeros(B, 4, device=self.device))
+        cg, keep = self._guidance(g, B)
+        out = torch.empty(B, 4, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_guidance_losses(self._h, _ptr(traj), C.byref(cg), _ptr(out), B, self._stream()), "cld_guidance_losses")
+        return out
 
     def guidance_step(self, mean, cond, guidance: Mapping, sigma: float, z=None, want_grad=False):
         """One guidance step on a posterior mean [B,52,4] (upstream PerturbationGuidance.perturb, guidance_loss.py:2221-2282)
@@ -297,7 +343,8 @@ class Engine:
         n = self.loop_steps                 # loop iterations = noise slabs (n_timesteps with the reference's stride 1)
         noise = None if noise is None else self._f32(noise, (n, B, T, D))
         x0 = torch.empty_like(x_T)
-        x1 = torch.empty_like(x_T) if (want_x1 and self.stride == 1) else None      # step 1 is only visited with stride 1
+        # x1 exists only when the loop visits step 1 (dm_model.py:126-127): stride 1 and at least two timesteps
+        x1 = torch.empty_like(x_T) if (want_x1 and 1 in range(0, self.n_timesteps, self.stride)) else None
         logp = torch.empty(B, dtype=torch.float32, device=self.device) if want_logp else None
         cfg = non_cond is not None and guidance_w != 0.0
         with torch.cuda.device(self.device):

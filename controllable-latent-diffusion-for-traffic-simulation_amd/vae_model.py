@@ -41,6 +41,7 @@ class LSTMVAE:
 class VaeModel:
     def __init__(self, algo_config=None, train_config=None, modality_shapes=None, device="cuda:0",
                  engine: Optional[Engine] = None):
+        self._owns_engine = engine is None       # standalone VaeModel: a handle without U-Net weights (cld_finalize allows it)
         self.engine = engine or Engine(device=device, dynamics=cfg_get(algo_config, "dynamics"),
                                        norm_info=cfg_get(algo_config, "nusc_norm_info.diffuser"))
         self.lstmvae = LSTMVAE(self.engine)
@@ -52,7 +53,12 @@ class VaeModel:
         self.div_coeffs = torch.tensor(list(c.norm_std), dtype=torch.float32)
 
     def load_state_dict(self, sd, strict=True):
+        """Weights under the reference's `lstmvae.*` / `context_encoder.*` names.  A VaeModel that owns its engine finalizes it
+        here (decoder / encoder / ContextEncoder calls work, U-Net calls report the missing weights); with a shared engine
+        (`engine=`) the DmModel's load_state_dict finalizes, so load the VAE weights first."""
         self.engine.load_state_dict(sd, strict=strict)
+        if self._owns_engine:
+            self.engine.finalize()
         return self
 
     def pre_vae(self, batch):

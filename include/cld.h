@@ -117,7 +117,9 @@ int cld_unet_forward_t(cld_handle h, const float* x, const float* cond, const in
 /* The forward half of DmModel.compute_losses (dm_model.py:82-96; src/trainers/dm_trainer.py:84-90 validation_step):
  * z_t = q_sample(z0, t, noise) = sqrt(acp[t]) z0 + sqrt(1 - acp[t]) noise, eps = U-Net(z_t, cond, t) and
  * mse[b] = mean_{T,D} (noise - eps)^2, so that F.mse_loss(noise, eps) = mean_b mse[b].  z0, noise [B,52,4]; t_idx [B]
- * DEVICE int32; z_noisy [B,52,4] optional (NULL to skip).  Forward only: training itself is out of scope. */
+ * DEVICE int32 (values in [0, n_timesteps): the caller checks the range, the kernels index tables with them); z_noisy
+ * [B,52,4] optional (NULL to skip); mse NULL (then cond may be NULL too) = q_sample alone, no U-Net evaluation
+ * (DmModel.q_sample, dm_model.py:91-96).  Forward only: training itself is out of scope. */
 int cld_denoise_loss(cld_handle h, const float* z0, const float* noise, const float* cond, const int32_t* t_idx, float* z_noisy,
                      float* mse, int32_t B, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -199,6 +201,16 @@ typedef struct cld_guidance {
      * are torch code on that trajectory.  The step then uses J^T ext_grad, J = d traj / d mean (decoder + roll-out); with
      * cld_guidance_step(..., grad) this is the vector-Jacobian product itself.  NULL = no such term. */
     const float* ext_grad;
+    /* Guidance on the t = 0 OUTPUT of the chain (upstream `apply_guidance_output`, diffuser.py:877-880; off in upstream's
+     * defaults, scene_edit_config.py:84-91): when non-zero the final posterior mean takes one optimiser step with its own
+     * settings (`final_step_opt_params`) and x0 is the guided mean (no noise is added at t = 0).  apply_intermediate == 0
+     * switches the per-step guidance at t > 0 off (upstream `apply_guidance_intermediate`); the struct zero-initialised keeps
+     * the defaults: intermediate on, output off.  Fields follow lr / perturb_th / optimizer above. */
+    int32_t apply_output;
+    int32_t no_intermediate;
+    float final_lr;
+    float final_perturb_th;
+    int32_t final_optimizer;
 } cld_guidance;
 
 /* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */
@@ -287,6 +299,18 @@ int cld_compute_reward(cld_handle h, const float* traj, const float* traj_scaled
                        const uint8_t* drivable_map, int32_t H, int32_t W, const float* other_pos, const uint8_t* other_avail,
                        int32_t S, int32_t T_other, float collision_thresh, float* reward, float* offroad, float* collision,
                        int32_t B, void* stream);
+
+/* Per-agent values of the built-in guidance losses on decoded trajectories, as upstream reports them in `guide_losses`
+ * (DiffuserGuidance.compute_guidance_loss, src/tbsim/utils/guidance_loss.py:2143-2172: the unweighted `(B, N)` value of each
+ * loss; diffuser.py:924-926 evaluates them on the final output for sample selection, algos.py:2057-2064):
+ *   losses[b,0] TargetSpeedLoss        mean_t |v_t - target_speed[b,t]|                    (guidance_loss.py:219-254)
+ *   losses[b,1] SpeedLimitLoss         mean_t relu(|v_t| - speed_limit)                    (:1509-1538)
+ *   losses[b,2] AccLimitLoss           mean_t relu(|acc_t| - acc_limit)                    (:1444-1467)
+ *   losses[b,3] TargetPosAtTimeLoss    |(x, y)[target_time[b]] - target_pos[b]|            (:632-670), or for target_time < 0
+ *               TargetPosLoss          mean_{t >= m} softmin_t(dist) dist_t^2              (:672-716)
+ * A term that is off for agent b (its pointer NULL or its scale[b] == 0) is NaN, as upstream fills agents outside a loss's mask.
+ * traj [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate) as cld_decode returns it; losses [B,4]. */
+int cld_guidance_losses(cld_handle h, const float* traj, const cld_guidance* guidance, float* losses, int32_t B, void* stream);
 
 /* Closed-loop kinematic update of EnvUnifiedSimulation._step (src/tbsim/envs/env_trajdata.py:452-468) for plan step k
  * (the last of the n_step_action executed steps): traj [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate) in the agent frame

@@ -462,9 +462,12 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
 
 def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor,
                   loss_scale: Optional[Tensor] = None, lr: Optional[float] = 0.3, optimizer: str = "adam",
-                  non_cond: Optional[Tensor] = None, guidance_w: float = 0.0, clip_to_sigma: bool = False) -> dict:
+                  non_cond: Optional[Tensor] = None, guidance_w: float = 0.0, clip_to_sigma: bool = False,
+                  output: Optional[dict] = None) -> dict:
     """The ancestral loop of dm_model.py:119-132 with upstream's p_sample guidance (diffuser.py:844-929): steps t > 0
-    perturb the posterior mean before the noise is added (lr None -> sigma_t); t = 0 is unguided."""
+    perturb the posterior mean before the noise is added (lr None -> sigma_t); t = 0 is unguided unless `output` =
+    dict(lr, optimizer) is given: upstream's apply_guidance_output with its final_step_opt_params (diffuser.py:877-880;
+    the perturb_th of those never acts, see guidance_step)."""
     n = sched["betas"].shape[0]
     x = x_T
     x1 = None
@@ -478,10 +481,151 @@ def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: 
         if i > 0:
             mean, _ = guidance_step(wdec, mean, cond, cs, target_speed, loss_scale, sigma if lr is None else lr,
                                     sigma if clip_to_sigma else None, optimizer)
+        elif output is not None:
+            mean, _ = guidance_step(wdec, mean, cond, cs, target_speed, loss_scale, output.get("lr", 0.3), None, output.get("optimizer", "adam"))
         x = mean + (0.0 if i == 0 else sigma) * noise[s_]
         if i == 1:
             x1 = x.clone()
     return {"pred_traj": x, "x1": x1}
+
+
+# --------------------------------------------------------------------------- #
+# f-2  policy surface: guide-loss values, sample selection, world update, closed loop
+# --------------------------------------------------------------------------- #
+def guidance_losses(traj: Tensor, target_speed: Optional[Tensor] = None, loss_scale: Optional[Tensor] = None, speed_limit=None,
+                    acc_limit=None, target_pos=None) -> Tensor:
+    """The unweighted per-agent values upstream's guidance losses return (what DiffuserGuidance.compute_guidance_loss stores in
+    `guide_losses`, guidance_loss.py:2143-2172) on decoded trajectories [B,52,6] -> [B,4] = (TargetSpeedLoss :219-254,
+    SpeedLimitLoss :1509-1538, AccLimitLoss :1444-1467, TargetPosAtTimeLoss :632-670 | TargetPosLoss :672-716); NaN where a
+    term is off for the agent (upstream: agents outside the loss's mask, :2167-2169).  Argument conventions as `guidance_step`."""
+    B = traj.shape[0]
+    out = torch.full((B, 4), float("nan"), dtype=traj.dtype)
+    if target_speed is not None:
+        on = torch.ones(B, dtype=torch.bool) if loss_scale is None else loss_scale != 0
+        dev = torch.nan_to_num((traj[..., 2] - target_speed).abs(), nan=0.0)
+        out[on, 0] = dev.mean(dim=-1)[on]
+    if speed_limit is not None:
+        on = speed_limit[1] != 0
+        out[on, 1] = (traj[..., 2].abs() - speed_limit[0]).clamp(min=0).mean(dim=-1)[on]
+    if acc_limit is not None:
+        on = acc_limit[1] != 0
+        out[on, 2] = (traj[..., 4].abs() - acc_limit[0]).clamp(min=0).mean(dim=-1)[on]
+    if target_pos is not None:
+        p_, t_, s_ = target_pos
+        for b in range(B):
+            if float(s_[b]) == 0.0:
+                continue
+            tb = int(t_[b])
+            if tb >= 0:
+                out[b, 3] = (traj[b, min(tb, 51), :2] - p_[b]).norm()
+            else:
+                e = traj[b, min(-tb - 1, 51):, :2] - p_[b]
+                out[b, 3] = (F.softmin(e.norm(dim=-1), dim=-1) * (e ** 2).sum(dim=-1)).mean()
+    return out
+
+
+SCENE_LEVEL_LOSSES = ("agent_collision", "social_group", "gptcollision", "gptkeepdistance")
+
+
+def choose_action_from_guidance(guide_losses: Dict[str, Tensor], guide_config_names) -> Tensor:
+    """guidance_loss.py:22-66 for the agent-centric layout (preds [M,N,T,2], B = 1): `guide_losses` maps
+    '<name>_scene_%03d_%02d' -> [M,N] (NaN outside the loss's agents), stacked in dict order; `guide_config_names` is the
+    per-scene list of loss names (`guide_configs[si][g].name`).  Restated as written, INCLUDING its quirk: every scene's
+    result overwrites `act_idx` for the whole batch (the scene mask is commented out, :49-50,62-63), so the returned
+    indices are the LAST scene's -- agents outside it see an all-NaN row, nansum 0, argmin 0."""
+    accum = torch.stack([v for v in guide_losses.values()], dim=2)                 # [M, N, total number of losses]
+    M, N = accum.shape[:2]
+    act_idx = torch.zeros(M, dtype=torch.long)
+    scount = 0
+    for names in guide_config_names:
+        ends = scount + len(names)
+        scene_loss = torch.nansum(accum[..., scount:ends], dim=-1)                   # [M, N]
+        scount = ends
+        if any(nm in SCENE_LEVEL_LOSSES for nm in names):                            # one sample index for the whole scene (B = 1)
+            act_idx = torch.argmin(scene_loss.reshape(1, M, N).sum(dim=1), dim=1).unsqueeze(-1).expand(1, M).reshape(M)
+        else:
+            act_idx = torch.argmin(scene_loss, dim=-1)
+    return act_idx
+
+
+def choose_action_from_gt(positions: Tensor, target_positions: Tensor, target_availabilities: Tensor) -> Tensor:
+    """guidance_loss.py:67-99: the sample with the smallest average displacement from the ground-truth future over its valid
+    steps; rows whose every step is invalid keep sample 0.  positions [M,N,T,2]."""
+    M, N, T_ = positions.shape[:3]
+    endT = min(T_, target_positions.shape[1])
+    err = torch.norm(positions[:, :, :endT] - target_positions[:, :endT].unsqueeze(1), dim=-1)
+    valid = target_availabilities[:, :endT].unsqueeze(1).expand(M, N, endT).bool()
+    err = torch.where(valid, err, torch.full_like(err, float("nan")))
+    ade = torch.nanmean(err, dim=-1)
+    ok = torch.isnan(ade).sum(dim=-1) == 0
+    act_idx = torch.zeros(M, dtype=torch.long)
+    if bool(ok.any()):
+        act_idx[ok] = torch.argmin(ade, dim=-1)[ok]
+    return act_idx
+
+
+def world_step(traj: Tensor, centroid: Tensor, yaw: Tensor, k: int):
+    """EnvUnifiedSimulation._step, src/tbsim/envs/env_trajdata.py:452-468, for action index k: the planned state k (agent
+    frame at planning time) placed in the world: xy' = p_k @ [[c, s], [-s, c]] + centroid, h' = yaw + yaw_k.  Returns
+    (world [B,3] = (x, y, h), next curr_states [B,4] = (0, 0, v_k, 0): the agent-centric state the next planning call
+    conditions on, batch_utils.py:46-65)."""
+    c, s_ = torch.cos(yaw), torch.sin(yaw)
+    px, py = traj[:, k, 0], traj[:, k, 1]
+    wx = px * c - py * s_ + centroid[:, 0]
+    wy = px * s_ + py * c + centroid[:, 1]
+    world = torch.stack([wx, wy, yaw + traj[:, k, 3]], dim=1)
+    cs = torch.zeros(traj.shape[0], 4, dtype=traj.dtype)
+    cs[:, 2] = traj[:, k, 2]
+    return world, cs
+
+
+def closed_loop(w, wdec, sched, cond_fn, centroid: Tensor, yaw: Tensor, cs: Tensor, x_T: Tensor, noise: Tensor, n_sim_steps: int,
+                n_step_action: int = 5) -> Tensor:
+    """The loop of rollout_episodes (src/tbsim/utils/env_utils.py:255-304): observation -> plan (sample + decode, sample 0
+    executed) -> the world takes `n_step_action` steps of the plan (env_trajdata.py:452-468) -> re-plan.  `cond_fn(step, world,
+    curr_states) -> cond_feat` stands in for observation + ContextEncoder; the same x_T / noise feed every planning call.
+    Returns the world poses after each sim step [n_sim_steps, B, 3]."""
+    world = torch.cat([centroid, yaw[:, None]], dim=1)
+    poses = []
+    for step in range(n_sim_steps):
+        cond = cond_fn(step, world, cs)
+        out = sample(w, sched, x_T, noise, cond)
+        traj = decode(wdec, out["pred_traj"], cond, cs, True)
+        world, cs = world_step(traj, world[:, :2], world[:, 2], n_step_action - 1)
+        poses.append(world)
+    return torch.stack(poses)
+
+
+def get_action(w, wdec, sched, cond: Tensor, cs: Tensor, x_T: Tensor, noise: Tensor, num_samp: int = 1, guidance: Optional[dict] = None,
+               guide_config_names=None, filter_only: bool = False, stationary_th: Optional[float] = None):
+    """The get_action contract of upstream's DiffuserTrafficModel (src/tbsim/algos/algos.py:2024-2099) over this path:
+    repeat every agent num_samp times (dm_model.py:116), sample (guided on the steps t > 0 unless `filter_only`,
+    algos.py:1815), decode, evaluate the guidance losses on the final output (diffuser.py:924-926) and execute the sample
+    `choose_action_from_guidance` picks (sample 0 without guidance, algos.py:2053-2054); stationary agents are zeroed
+    (algos.py:2076-2083).  `guidance` = dict(target_speed [B,52], loss_scale [B] | None) (per-agent tensors are repeated
+    like the batch).  Returns (positions [B,52,2], yaws [B,52,1], act_idx [B], trajectories [B,N,52,6], guide losses [B,N,4] | None)."""
+    B, N = cond.shape[0], num_samp
+    rep = lambda v: v if v is None else v.repeat_interleave(N, dim=0)
+    cond_r, cs_r = rep(cond), rep(cs)
+    if guidance is not None and not filter_only:
+        out = sample_guided(w, wdec, sched, x_T, noise, cond_r, cs_r, rep(guidance["target_speed"]), rep(guidance.get("loss_scale")),
+                            lr=guidance.get("lr", 0.3), optimizer=guidance.get("optimizer", "adam"))
+    else:
+        out = sample(w, sched, x_T, noise, cond_r)
+    traj = decode(wdec, out["pred_traj"], cond_r, cs_r, True).reshape(B, N, 52, 6)
+    act_idx = torch.zeros(B, dtype=torch.long)
+    gl = None
+    if guidance is not None:
+        gl = guidance_losses(traj.reshape(B * N, 52, 6), rep(guidance["target_speed"]), rep(guidance.get("loss_scale"))).reshape(B, N, 4)
+        names = guide_config_names if guide_config_names is not None else [["target_speed"]]
+        act_idx = choose_action_from_guidance({"target_speed_scene_000_00": gl[..., 0]}, names)
+    pos, yaw_ = traj[..., :2].clone(), traj[..., 3:4].clone()
+    if stationary_th is not None:
+        still = cs[:, 2].abs() < stationary_th
+        pos[still] = 0
+        yaw_[still] = 0
+    ar = torch.arange(B)
+    return pos[ar, act_idx], yaw_[ar, act_idx], act_idx, traj, gl
 
 
 # --------------------------------------------------------------------------- #

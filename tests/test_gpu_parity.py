@@ -102,7 +102,7 @@ def test_ddpm_step_golden(golden, eng_jitter):
         assert sigma == pytest.approx(float(g[f"sigma_t{i}"][0]), rel=2e-6)
 
 
-@pytest.mark.parametrize("n,jitter", [(10, True), (100, False), (100, True)])
+@pytest.mark.parametrize("n,jitter", [(10, True), (50, True), (100, False), (100, True)])
 def test_full_chain_golden(golden, n, jitter):
     meta, g = golden(f"sample_n{n}_{'jitter' if jitter else 'default'}")
     e = _engine(n, jitter, decoder=False)
@@ -823,3 +823,227 @@ def test_encode_mfma_kernel_vs_oracle_and_valu():
     for k in ("mfma", "valu"):
         for got, want in zip(outs[k], ref):
             assert (got.cpu() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), k
+
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: schedule buffers, the absolute bar, configs[4] pieces, the get_action contract
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [10, 50, 100])
+def test_schedule_buffers_golden(golden, n):
+    """a-1 directly: the three buffers the sampler reads (dm_model.py:29-56), rebuilt in C++ by cld_create and returned by
+    cld_get_schedule, against the reference's own buffers: <= 1 ulp (the C++ libm and numpy / torch may round cos / log /
+    sqrt differently in the last bit)."""
+    from cld_amd.engine import Engine
+    _, g = golden(f"schedule_n{n}")
+    e = Engine(n_timesteps=n, device="cuda:0")
+    for name in ("x_t_cof", "noise_cof", "posterior_log_variance_clipped"):
+        got, ref = getattr(e, name), g[name]
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref))), (name, np.abs(got - ref).max())
+    assert e.posterior_log_variance_clipped[0] == np.float32(np.log(np.float32(1e-20)))       # the 1e-20 clamp -> sigma_0 = 1e-10
+
+
+def test_small_chain_absolute_bar(golden):
+    """north_star's literal bar end to end: a 100-step chain recorded from the reference whose x0 stays O(1) (output layer and
+    inputs scaled down, fixture sample_n100_small), so `<= 1e-3 per latent element` is an ABSOLUTE check here."""
+    from cld_amd.engine import Engine
+    from tests.test_oracle_golden import small_chain_inputs
+    meta, g = golden("sample_n100_small")
+    w, x_T, noise = small_chain_inputs(meta)
+    e = Engine(n_timesteps=meta["n_timesteps"], device="cuda:0", precision=PRECISION)
+    e.load_state_dict(w)
+    e.finalize()
+    cond = torch.from_numpy(synth.make_inputs(meta["B"], meta["in_seed"])["cond_feat"])
+    x0, x1, logp = e.sample(x_T, cond, noise=noise)
+    scale = float(np.abs(g["pred_traj"]).max())
+    assert scale <= 10.0
+    for got, k in ((x0, "pred_traj"), (x1, "x1")):
+        err = float(np.abs(got.cpu().numpy() - g[k]).max())
+        print(f"small chain {k}: max|d|={err:.3e} max|ref|={scale:.3e}")
+        assert err <= 1e-3
+    assert np.allclose(logp.cpu().numpy(), g["log_prob_final"], atol=1e-4)
+
+
+def test_guidance_loss_values_golden(golden, eng_jitter):
+    """cld_guidance_losses against the reference's own loss classes (fixture guide_losses) and NaN for the terms that are off."""
+    meta, g = golden("guide_losses")
+    B, N = meta["B"], meta["N"]
+    x = torch.from_numpy(synth.normal(meta["in_seed"], "gl_traj", (B, N, 52, 6))) * torch.tensor([20.0, 5.0, 6.0, 0.5, 3.0, 0.2])
+    tgt = torch.from_numpy(synth.uniform(meta["in_seed"], "gl_tgt", (B, 52), 0.0, 12.0))
+    wp = torch.from_numpy(synth.uniform(meta["in_seed"], "gl_wp", (B, 2), -5.0, 25.0))
+    rep = lambda v: v.repeat_interleave(N, dim=0)
+    one = torch.ones(B * N)
+    flat = x.reshape(B * N, 52, 6)
+    a = eng_jitter.guidance_losses(flat, {"target_speed": rep(tgt), "speed_limit": (meta["speed_limit"], one), "acc_limit": (meta["acc_limit"], one),
+                                          "target_pos": (rep(wp), rep(torch.tensor(meta["target_time"])), one)}).reshape(B, N, 4).cpu().numpy()
+    m = int(meta["min_target_time"] * 52)
+    b = eng_jitter.guidance_losses(flat, {"target_pos": (rep(wp), torch.full((B * N,), -(m + 1)), one)}).reshape(B, N, 4).cpu().numpy()
+    for col, key in ((0, "target_speed"), (1, "speed_limit"), (2, "acc_limit"), (3, "target_pos_at_time")):
+        assert np.abs(a[..., col] - g[key]).max() <= 2e-6 * max(1.0, np.abs(g[key]).max()), key
+    assert np.abs(b[..., 3] - g["target_pos"]).max() <= 2e-5 * max(1.0, np.abs(g["target_pos"]).max())
+    assert np.isnan(b[..., :3]).all()
+    # a zero scale switches the term off for that agent
+    half = one.clone(); half[::2] = 0.0
+    c = eng_jitter.guidance_losses(flat, {"speed_limit": (4.0, half)}).cpu().numpy()
+    assert np.isnan(c[::2, 1]).all() and not np.isnan(c[1::2, 1]).any()
+
+
+def _policy(eng):
+    from cld_amd.dm_model import DmModel
+    from cld_amd.policy import CldPolicy
+    from cld_amd.vae_model import VaeModel
+    return CldPolicy(DmModel(None, None, n_timesteps=eng.n_timesteps, engine=eng), VaeModel(engine=eng))
+
+
+def test_get_action_selects_the_sample_upstream_would(golden, eng10):
+    """get_action with guidance active (algos.py:2053-2064): per-sample guidance losses come back as info['guide_losses'] (equal to
+    the oracle's on the same trajectories), the executed sample is the oracle's `choose_action_from_guidance` of them -- whose
+    behaviour is pinned by fixture `select` recorded from the reference's own function -- and `guide_as_filter_only` samples
+    without guidance and only filters (algos.py:1815)."""
+    from oracle import cld_oracle as O
+    pol = _policy(eng10)
+    B, N = 6, 4
+    inp = synth.make_inputs(B, 13)
+    cond, cs = torch.from_numpy(inp["cond_feat"]).cuda(), torch.from_numpy(inp["curr_states"]).cuda()
+    tgt = synth.uniform(13, "tgt", (B, 52), 0.0, 12.0)
+    cfg = [[{"name": "target_speed", "weight": 1.0, "params": {"target_speed": tgt}, "agents": None}],
+           [{"name": "target_speed", "weight": 2.0, "params": {"target_speed": tgt}, "agents": None},
+            {"name": "speed_limit", "weight": 1.0, "params": {"speed_limit": 5.0}, "agents": [0, 2]}]]
+    scene_index = torch.tensor([0, 0, 1, 1, 1, 1])
+    pol.set_guidance(cfg, scene_index, lr=0.3, optimizer="adam")
+    nz = synth.make_noise(B * N, 10, 5)
+    noise = {"x_T": torch.from_numpy(nz["x_T"]), "noise": torch.from_numpy(nz["noise"])}
+    act, info = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise, step_index=0)
+    traj = info["trajectories"]
+    gl = info["guide_losses"]
+    assert list(gl) == ["target_speed_scene_000_00", "target_speed_scene_001_00", "speed_limit_scene_001_01"]
+    # loss values vs the oracle on the same decoded trajectories; NaN outside each loss's agents
+    tr = traj.reshape(B * N, 52, 6).cpu()
+    rep = lambda v: torch.as_tensor(v).repeat_interleave(N, dim=0)
+    ref = O.guidance_losses(tr, rep(tgt), None, (5.0, torch.ones(B * N)), None, None).reshape(B, N, 4)
+    for key, col, members in (("target_speed_scene_000_00", 0, [0, 1]), ("target_speed_scene_001_00", 0, [2, 3, 4, 5]),
+                              ("speed_limit_scene_001_01", 1, [2, 4])):
+        got = gl[key].cpu()
+        out = [b for b in range(B) if b not in members]
+        assert bool(torch.isnan(got[out]).all()), key
+        assert float((got[members] - ref[members, :, col]).abs().max()) <= 1e-5 * max(1.0, float(ref[members, :, col].abs().max())), key
+    want = O.choose_action_from_guidance({k: v.cpu() for k, v in gl.items()}, [["target_speed"], ["target_speed", "speed_limit"]])
+    assert torch.equal(info["act_idx"].cpu(), want)
+    assert bool((want[:2] == 0).all()) and bool((want[2:] != 0).any())           # upstream: the last scene's choice, sample 0 elsewhere
+    ar = torch.arange(B)
+    assert torch.equal(act.positions.cpu(), traj[..., :2].cpu()[ar, want]) and torch.equal(act.yaws.cpu(), traj[..., 3:4].cpu()[ar, want])
+    # the evident intent (every scene chooses for its own agents) is available as an option
+    pol.select_per_scene = True
+    _, info2 = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise)
+    s0 = torch.nansum(torch.stack([gl["target_speed_scene_000_00"]], 2), 2).argmin(dim=-1).cpu()
+    assert torch.equal(info2["act_idx"].cpu()[:2], s0[:2]) and torch.equal(info2["act_idx"].cpu()[2:], want[2:])
+    pol.select_per_scene = False
+    # filter only: the samples are the UNGUIDED chain's, the selection still follows the guidance losses
+    _, info3 = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise, guide_as_filter_only=True)
+    pol.clear_guidance()
+    _, info0 = pol.get_action({"cond_feat": cond, "curr_states": cs}, num_action_samples=N, noise=noise)
+    assert torch.equal(info3["trajectories"], info0["trajectories"]) and not torch.equal(info3["trajectories"], traj)
+    assert "guide_losses" in info3 and "guide_losses" not in info0 and bool((info0["act_idx"] == 0).all())
+    # the sample closest to the ground-truth future (algos.py:2055-2056; upstream's own helper raises NameError as written)
+    gt = info0["trajectories"][:, 2, :40, :2].clone()                      # sample 2 is the truth for every agent ...
+    avail = torch.ones(B, 40, dtype=torch.bool); avail[1] = False          # ... except agent 1, which has no valid step
+    _, info4 = pol.get_action({"cond_feat": cond, "curr_states": cs, "target_positions": gt, "target_availabilities": avail},
+                              num_action_samples=N, noise=noise, guide_with_gt=True)
+    assert info4["act_idx"].cpu().tolist() == [2, 0, 2, 2, 2, 2]
+    assert torch.equal(info4["act_idx"].cpu(), O.choose_action_from_gt(info0["trajectories"][..., :2].cpu(), gt.cpu(), avail))
+
+
+def test_get_action_rejects_what_it_does_not_implement(eng10):
+    """No silent **kwargs: options of upstream's get_action that are not built raise, unknown names are a TypeError, and
+    classifier-free guidance without unconditional features is an error instead of an unguided run."""
+    from cld_amd._lib import CldError
+    pol = _policy(eng10)
+    B = 3
+    inp = synth.make_inputs(B, 2)
+    obs = {"cond_feat": torch.from_numpy(inp["cond_feat"]).cuda(), "curr_states": torch.from_numpy(inp["curr_states"]).cuda()}
+    with pytest.raises(NotImplementedError):
+        pol.get_action(obs, guide_clean=True)
+    with pytest.raises(NotImplementedError):
+        pol.get_action(obs, plan=object())
+    with pytest.raises(TypeError):
+        pol.get_action(obs, not_an_option=1)
+    with pytest.raises(CldError):                      # eng10 has no ContextEncoder weights to build non_cond_feat from
+        pol.get_action(obs, class_free_guide_w=2.0)
+    with pytest.raises(CldError):
+        pol.dm({"history_positions": obs["cond_feat"]}, obs, {"num_samp": 1}, class_free_guide_w=2.0)
+    with pytest.raises(CldError):                      # per-row timesteps are range-checked on the host
+        eng10.unet_forward_rows(torch.zeros(B, 52, 4), obs["cond_feat"], torch.tensor([0, 3, 10]))
+
+
+def test_guidance_on_the_output_step_vs_oracle(eng10):
+    """upstream apply_guidance_output (diffuser.py:877-880): the t = 0 posterior mean takes one more optimiser step with
+    final_step_opt_params and no noise follows -- against the oracle's autograd chain; `intermediate=False` leaves only that step."""
+    from oracle import cld_oracle as O
+    B, n = 6, 10
+    inp = synth.make_inputs(B, 17)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    tgt = torch.from_numpy(synth.uniform(17, "tgt", (B, 52), 0.0, 12.0))
+    nz = synth.make_noise(B, n, 6)
+    xT, noise = torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"])
+    gd = {"curr_states": cs, "target_speed": tgt, "lr": 0.3, "optimizer": "adam", "output": {"lr": 0.2, "optimizer": "sgd", "perturb_th": 1.0}}
+    x0, _, _ = eng10.sample(xT, cond, noise=noise, guidance=gd)
+    torch.set_num_threads(8)
+    w, wd = O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), O.to_torch(synth.make_decoder_weights(0))
+    ref = O.sample_guided(w, wd, O.schedule(n), xT, noise, cond, cs, tgt, lr=0.3, optimizer="adam", output={"lr": 0.2, "optimizer": "sgd"})["pred_traj"]
+    plain = O.sample_guided(w, wd, O.schedule(n), xT, noise, cond, cs, tgt, lr=0.3, optimizer="adam")["pred_traj"]
+    scale = float(ref.abs().max())
+    assert float((x0.cpu() - ref).abs().max()) <= 1e-3 * scale
+    assert float((plain - ref).abs().max()) > 1e-4 * scale                 # the output step did something
+    only, _, _ = eng10.sample(xT, cond, noise=noise, guidance=dict(gd, intermediate=False))
+    base, _, _ = eng10.sample(xT, cond, noise=noise)
+    mean_g = eng10.guidance_step(base, cond, {"curr_states": cs, "target_speed": tgt, "lr": 0.2, "optimizer": "sgd"}, sigma=0.0)
+    assert float((only - mean_g).abs().max()) <= 1e-5 * float(base.abs().max())
+
+
+def test_closed_loop_vs_oracle(eng10):
+    """configs[4]'s loop at oracle size: encode-free planning loop (cond_fn supplies cond_feat) -> sample -> decode -> world update,
+    3 sim steps of 8 agents, against oracle.closed_loop (env_utils.py:255-304 + env_trajdata.py:452-468)."""
+    from cld_amd.policy import closed_loop_rollout
+    from oracle import cld_oracle as O
+    pol = _policy(eng10)
+    B, n, S = 8, 10, 3
+    inp = synth.make_inputs(B, 23)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    conds = [cond, cond.flip(0).contiguous(), (cond * 0.5).contiguous()]
+    ctr = torch.from_numpy(synth.normal(23, "ctr", (B, 2))) * 50.0
+    yaw = torch.from_numpy(synth.uniform(23, "yaw", (B,), -3.1, 3.1))
+    nz = synth.make_noise(B, n, 8)
+    xT, noise = torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"])
+    poses = closed_loop_rollout(pol, lambda s, wld, c: conds[s].cuda(), ctr, yaw, cs, n_sim_steps=S,
+                                noise={"x_T": xT, "noise": noise}).cpu()
+    torch.set_num_threads(8)
+    w, wd = O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), O.to_torch(synth.make_decoder_weights(0))
+    with torch.no_grad():
+        ref = O.closed_loop(w, wd, O.schedule(n), lambda s, wld, c: conds[s], ctr, yaw, cs, xT, noise, S)
+    # poses are O(100 m); the plan's positions carry the chain's relative error (1e-3 of max|x0| through the decoder is far below this)
+    assert float((poses - ref).abs().max()) <= 2e-3, float((poses - ref).abs().max())
+    assert float((poses[-1, :, :2] - ctr).norm(dim=-1).min()) > 0.0
+
+
+def test_standalone_vae_model_without_unet_weights():
+    """VaeModel() on its own engine (no DmModel): cld_finalize accepts a handle without the U-Net; decoder / encoder calls
+    work and match the oracle, U-Net calls report the missing weights instead of crashing."""
+    from cld_amd._lib import CldError
+    from cld_amd.vae_model import VaeModel
+    from oracle import cld_oracle as O
+    vae = VaeModel(device="cuda:0")
+    vae.load_state_dict(dict(synth.make_decoder_weights(0), **synth.make_encoder_weights(0)))
+    B = 5
+    inp = synth.make_inputs(B, 71)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    z = torch.from_numpy(synth.normal(71, "z", (B, 52, 4)))
+    act = vae.lstmvae.lstm_dec(z, cond)
+    traj = vae.convert_action_to_state_and_action(act, cs, descaled_output=True)
+    wd = O.to_torch(synth.make_decoder_weights(0))
+    assert float((act.cpu() - O.lstm_decode(wd, z, cond)).abs().max()) <= 2e-5
+    assert float((traj.cpu() - O.decode(wd, z, cond, cs, True)).abs().max()) <= 1e-4
+    with pytest.raises(CldError, match="U-Net weights"):
+        vae.engine.unet_forward(z, cond, 3)
+    with pytest.raises(CldError, match="U-Net weights"):
+        vae.engine.sample(z, cond, noise=torch.zeros(100, B, 52, 4))

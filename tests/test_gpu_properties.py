@@ -334,3 +334,55 @@ def test_full_size_chain_vs_oracle(eng, oracle_w):
     assert float((x1.cpu() - ref["x1"]).abs().max()) <= 1e-3 * scale
     assert float((traj.cpu() - reft).abs().max()) <= 1e-3
     assert float((lp.cpu() - ref["log_prob_final"]).abs().max()) <= 1e-4
+
+
+def test_configs4_closed_loop_at_per_gpu_size(precision):
+    """BASELINE configs[4] on one GPU's shard: 64 scenes x 64 = 4,096 agents, 50 denoising steps per planning call, the loop
+    ContextEncoder-free (cond_feat supplied) -> sample -> decode -> VAE encode of the plan -> world update, 2 sim steps.
+    Size-independent property: agents are independent, so 40 rows picked across the batch and run as their own small batch
+    through the same loop land on the same poses (to the chain's rounding through decode: the small batch takes other tilings),
+    and the encoded plan's posterior matches row for row."""
+    from cld_amd.dm_model import DmModel
+    from cld_amd.engine import Engine
+    from cld_amd.policy import CldPolicy, closed_loop_rollout
+    from cld_amd.vae_model import VaeModel
+    n, B, S = 50, 4096, 2
+    e = Engine(n_timesteps=n, device="cuda:0", precision=precision)
+    for sd in (synth.make_unet_weights(0, affine_jitter=True), synth.make_decoder_weights(0), synth.make_encoder_weights(0)):
+        e.load_state_dict(sd)
+    e.finalize()
+    pol = CldPolicy(DmModel(None, None, n_timesteps=n, engine=e), VaeModel(engine=e))
+    g = torch.Generator(device="cuda").manual_seed(44)
+    conds = [torch.randn(B, 256, device="cuda", generator=g) for _ in range(S)]
+    xT = torch.randn(B, 52, 4, device="cuda", generator=g)
+    nz = torch.randn(n, B, 52, 4, device="cuda", generator=g)
+    cs = torch.zeros(B, 4, device="cuda"); cs[:, 2] = torch.rand(B, device="cuda", generator=g) * 15.0
+    ctr = torch.randn(B, 2, device="cuda", generator=g) * 100.0
+    yaw = (torch.rand(B, device="cuda", generator=g) - 0.5) * 6.0
+    encoded = []
+
+    def run(idx):
+        sel = (lambda t: t) if idx is None else (lambda t: t[idx].contiguous())
+        plans = []
+
+        def gather(traj):          # stands where the all-gather sits: keeps every executed plan, and re-encodes it (the "VAE encode" stage)
+            plans.append(traj)
+            sa = e.state_to_state_and_action(traj[..., :2].contiguous(), traj[..., 3:4].contiguous(), traj[:, 0, 2].contiguous(), scaled_output=True)
+            encoded.append(e.traj2z(sa, sel(conds[len(plans) - 1]), noise=None)[1])
+            return traj
+        poses = closed_loop_rollout(pol, lambda s, wld, c: sel(conds[s]), sel(ctr), sel(yaw), sel(cs), n_sim_steps=S, gather=gather,
+                                    noise={"x_T": sel(xT), "noise": nz if idx is None else nz[:, idx].contiguous()})
+        return poses, plans
+    poses, plans = run(None)
+    mu_big = [m.clone() for m in encoded]
+    encoded.clear()
+    assert poses.shape == (S, B, 3) and bool(torch.isfinite(poses).all()) and all(bool(torch.isfinite(m).all()) for m in mu_big)
+    idx = torch.cat([torch.tensor([0, 1, 63, 64, 2047, 2048, 4095], device="cuda"), torch.randint(0, B, (33,), device="cuda", generator=g)])
+    poses_s, plans_s = run(idx)
+    scale = max(1.0, float(plans[0][idx].abs().max()))
+    for s_ in range(S):
+        assert float((plans[s_][idx] - plans_s[s_]).abs().max()) <= 2e-3 * scale, s_
+        assert float((mu_big[s_][idx] - encoded[s_]).abs().max()) <= 2e-3 * max(1.0, float(mu_big[s_].abs().max())), s_
+    assert float((poses[:, idx] - poses_s).abs().max()) <= 2e-3 * max(1.0, float(poses.abs().max()))
+    again, _ = run(None)
+    assert torch.equal(again, poses)                   # deterministic

@@ -106,26 +106,51 @@ full = gather_trajectories(local)
 assert full.shape == (w * B, 52, 6)
 for q in range(w):
     assert torch.equal(full[q * B:(q + 1) * B], torch.full((B, 52, 6), float(q)) + torch.arange(B).reshape(B, 1, 1))
-spans = [shard_scenes(5, w, q) for q in range(w)]            # uneven split: 3 + 2 scenes
+spans = [shard_scenes(5, w, q) for q in range(w)]            # uneven split: 3 + 2 scenes (2 + 2 + 1 over three ranks)
 sizes = [(h - l) * 4 for l, h in spans]
 lo, hi = spans[r]
 mine = torch.arange(lo * 4, hi * 4, dtype=torch.float32).reshape(-1, 1, 1).expand(-1, 52, 6).contiguous()
 allr = gather_ragged(mine, sizes)
 assert allr.shape == (20, 52, 6) and torch.equal(allr[:, 0, 0], torch.arange(20, dtype=torch.float32))
+# BASELINE configs[3]: the fixed job of 1,024 scenes sharded by scene over this world (one row per scene here): every rank
+# ends up with every scene's row in scene order, whether the split is even or not (bench.py --gpus N for N in 3, 5, 6, 7)
+spans = [shard_scenes(1024, w, q) for q in range(w)]
+sizes = [h - l for l, h in spans]
+lo, hi = spans[r]
+mine = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1, 1).expand(-1, 52, 6).contiguous()
+allr = gather_ragged(mine, sizes) if len(set(sizes)) > 1 else gather_trajectories(mine)
+assert allr.shape == (1024, 52, 6) and torch.equal(allr[:, 51, 5], torch.arange(1024, dtype=torch.float32))
 dist.barrier(); dist.destroy_process_group()
 print("rank", r, "ok")
 '''
 
 
-def test_gloo_world2_gather(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_gather_even_and_uneven_splits(tmp_path, world):
+    """The N > 1 exchange on the CPU (gloo): equal shards, a 3 + 2 scene split, and configs[3]'s 1,024 scenes over 2 ranks
+    (512 + 512, one all_gather_into_tensor) and over 3 ranks (342 + 341 + 341, the padded gather)."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, CLD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    env = dict(os.environ, CLD_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + world), WORLD_SIZE=str(world))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_scene_shards_cover_the_job_for_every_world_size():
+    """parallel.shard_scenes / shard_agents for BASELINE configs[3] (1,024 x 64) and configs[4] (512 x 64) at every rank count
+    the driver may use: contiguous, disjoint, complete, and at most one scene apart in size."""
+    from cld_amd.parallel import shard_agents, shard_scenes
+    for scenes in (1024, 512, 5):
+        for world in range(1, 9):
+            spans = [shard_scenes(scenes, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == scenes
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [h - l for l, h in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+            assert [shard_agents(scenes, 64, world, r) for r in range(world)] == [(l * 64, h * 64) for l, h in spans]
 
 
 def test_context_host_mirror_and_synthetic_inputs():
@@ -154,11 +179,12 @@ def test_guidance_struct_matches_header():
     g = _lib.CldGuidance
     assert [n for n, _ in g._fields_] == ["curr_states", "target_speed", "loss_scale", "lr", "perturb_th", "optimizer",
                                           "speed_limit", "acc_limit", "speed_limit_scale", "acc_limit_scale",
-                                          "target_pos", "target_time", "target_pos_scale", "ext_grad"]
-    assert ctypes.sizeof(g) == 96 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
+                                          "target_pos", "target_time", "target_pos_scale", "ext_grad",
+                                          "apply_output", "no_intermediate", "final_lr", "final_perturb_th", "final_optimizer"]
+    assert ctypes.sizeof(g) == 120 and g.apply_output.offset == 96 and g.final_optimizer.offset == 112 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
     hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
     body = hdr[hdr.index("typedef struct cld_guidance {"):hdr.index("} cld_guidance;")]
-    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad);", body)] == [n for n, _ in g._fields_]
+    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad|apply_output|no_intermediate|final_lr|final_perturb_th|final_optimizer);", body)] == [n for n, _ in g._fields_]
 
 
 def test_timers_keep_the_reference_surface():
