@@ -199,15 +199,17 @@ void build_schedule(cld_handle h) {
         betas[i] = (float)b;
         alphas[i] = 1.0f - betas[i];
     }
-    float run = 1.0f;
-    for (int i = 0; i < n; ++i) { acp_prev[i] = run; run = run * alphas[i]; acp[i] = run; }
-    acp_prev[0] = 1.0f;
+    // torch.cumprod on a CPU float tensor accumulates in DOUBLE and rounds every element to float (at::acc_type<float, false>):
+    // a sequential float product differs from the reference's buffer by up to 3 ulp at n = 100, which the cancellation in
+    // alphas - alphas_cumprod * alphas (noise_cof) then amplifies
+    double run = 1.0;
+    for (int i = 0; i < n; ++i) { run *= (double)alphas[i]; acp[i] = (float)run; acp_prev[i] = i ? acp[i - 1] : 1.0f; }
     h->x_t_cof.resize(n); h->noise_cof.resize(n); h->plvc.resize(n); h->sqrt_acp.resize(n); h->sqrt_1m_acp.resize(n);
     for (int i = 0; i < n; ++i) {
         h->sqrt_acp[i] = std::sqrt(acp[i]);                 // dm_model.py:36-37
         h->sqrt_1m_acp[i] = std::sqrt(1.0f - acp[i]);
         const float pv = betas[i] * (1.0f - acp_prev[i]) / (1.0f - acp[i]);
-        h->plvc[i] = std::log(pv < 1e-20f ? 1e-20f : pv);
+        h->plvc[i] = (float)std::log((double)(pv < 1e-20f ? 1e-20f : pv));      // correctly rounded: equals torch.log on every entry of the n = 10 / 50 / 100 tables
         h->x_t_cof[i] = std::sqrt(1.0f / alphas[i]);
         h->noise_cof[i] = betas[i] / std::sqrt(alphas[i] - acp[i] * alphas[i]);
     }
@@ -278,7 +280,8 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
     if (force && force[0] == 'C' && l.c_out == 256 && l.g.ntaps == 5 && l.g.stride == 1) return set(32, 4, 2);   // 8 waves: 64 columns x 2-way K split
     if (force && force[0] == 'A' && l.has_a) return set(32, 4, 1);
     if (force && force[0] == 'B' && l.has_b) return set(32, 2, 2);
-    if (l.has_a && (waves_a >= 2048 || !l.has_b)) return set(32, 4, 1);
+    const bool skip_a = force && force[0] == 'b';      // experiments: 32-column tiles (with CLD_TILING_HALF's height) at every batch size
+    if (l.has_a && ((waves_a >= 2048 && !skip_a) || !l.has_b)) return set(32, 4, 1);
     // tiling C for the 256-channel k5 blocks between 1,024 and 2,047 agents: 8-wave workgroups (64 columns x 2-way K split),
     // one per CU -- the same two waves per SIMD as B with half the A-image staging per MFMA (+1.4 % end to end at B = 1,024).
     // One C workgroup is two B workgroups' work on a CU, so in the units of the tile-height model below it costs
@@ -294,7 +297,7 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
         constexpr const char* tc = nullptr;
 #endif
         const bool widest_only = !(tc && tc[0] == 'a');
-        if (!force && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c)) {
+        if ((!force || skip_a) && !(tc && tc[0] == '0') && l.g.ain == 0 && wgs_c >= 256 && (!widest_only || l.c_out == 256) && conv_geom_supported(c)) {
             cost_c = (double)((wgs_c + 255) / 256) * 2 * 13 / 0.92 / 1.014;
             if (!l.has_b) return set(32, 4, 2);     // (64-channel chunks with this tiling: 918k vs 949k step.agent/s, not built)
         }
@@ -543,7 +546,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 2 || form < 0 || form > 2) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 2 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }

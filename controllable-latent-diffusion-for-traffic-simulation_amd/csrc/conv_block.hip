@@ -37,6 +37,14 @@ namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+// floats of one A image + its dump row (must match conv_body: ABUFP)
+constexpr int conv_image_floats(int l_in, int lm, int stride, int kc, int ain, int hm) {
+    const int ag = (208 >> hm) / lm;
+    const bool tmap = ain == 0 && hm == 0 && stride == 1 && kc == 32 && l_in == lm && (lm == 13 || lm == 26 || lm == 52);
+    const int aex = tmap ? (lm == 26 ? 16 : 0) : ((ain == 0 && stride == 1 && kc == 32) ? 48 : 0);
+    return (ag * (l_in + 2) + 2 + 1) * (kc + 8) + ag * aex;
+}
+
 
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)) == x * n / (n + 2), n = e^x (e^x + 2): one exp, no cancellation.
@@ -125,8 +133,26 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     constexpr int LP = L_IN + 2;           // LDS rows per agent (2 halo rows shared with the neighbour)
     constexpr int AROWS = AG * LP + 2;
     constexpr int KCP = KC + 8;            // padded LDS row (floats): strides 40 / 72 make the b128 fragment reads of 16 consecutive rows conflict-free
-    constexpr int ABUF = AROWS * KCP;      // floats per A image
+    // ... of 16 CONSECUTIVE LDS rows.  An M-tile's 16 GEMM rows cross agent boundaries, where the LDS row jumps by the 2 halo
+    // rows: with row stride 40 floats that shifts the bank pattern by a quarter turn and two of the four lane groups of every
+    // ds_read_b128 see 2-way conflicts (46 % of the LDS-array cycles of the dominant kernel were conflicts, round 1).  Two
+    // fixes, both free of extra LDS traffic:
+    //   TMAP: a full-height tile holds AG = 16 / 8 / 4 agents x 13 / 26 / 52 rows = 13 M-tiles of 16: M-tile m takes rows
+    //         RPT m .. RPT m + RPT - 1 (RPT = 16 / AG = 1 / 2 / 4) of EVERY agent, lane i = (agent i % AG, row RPT m + i / AG).
+    //         Consecutive lanes are then a whole agent block apart; with the block length 15 rows (L = 13), 28 rows + 16 floats
+    //         (L = 26) or 54 rows (L = 52) the 16 lanes of every read group land on 16 different 16-byte bank slots --
+    //         conflict-free (brute-forced over all tiles and lane groups), and the fragment address becomes AFFINE in m:
+    //         one VGPR + an immediate per M-tile instead of 13 VGPRs.
+    //   AEX : the partial-height tiles keep consecutive rows per tile; there every agent's block of rows is followed by 48
+    //         extra floats, which makes the jump at an agent boundary (2 rows + 48 floats = 32 sixteen-byte slots) a whole
+    //         number of bank turns.
+    constexpr int RPT = 16 / (AG > 16 ? 16 : AG);      // rows of one agent per M-tile under TMAP
+    constexpr bool TMAP = !SPLIT && HM == 0 && STRIDE == 1 && KC == 32 && L_IN == LM && AG * RPT == 16 && LM % RPT == 0 && NMT * RPT == LM;
+    constexpr int AEX = TMAP ? (LM == 26 ? 16 : 0) : ((!SPLIT && STRIDE == 1 && KC == 32) ? 48 : 0);
+    constexpr int ASTR = LP * KCP + AEX;   // floats from one agent's first row to the next agent's
+    constexpr int ABUF = AROWS * KCP + AG * AEX;      // floats per A image
     constexpr int ABUFP = ABUF + KCP;      // + one dump row for the staging pieces past the tile
+    static_assert(ABUFP == conv_image_floats(L_IN, LM, STRIDE, KC, AIN, HM), "launcher and kernel disagree on the LDS image size");
     constexpr int NT = 16 * NWN;
     constexpr int OP = NT + 4;             // padded row of the output tile
     constexpr int NKG = KC / 16;           // 16-channel groups per chunk
@@ -239,7 +265,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         // split mode: odd LDS rows keep the hi / lo planes of every 8-channel block swapped, so the two lanes of a
         // 16-lane read group that land on one 32-byte slot (rows 5 apart mod 8) take different 16-byte halves
         const int pcs = SPLIT ? (pc4 ^ (((2 + a * LP + l) & 1) << 2)) : pc4;
-        soff[i] = ok ? (2 + a * LP + l) * KCP + pcs : AROWS * KCP + pc4;
+        soff[i] = ok ? a * ASTR + (2 + l) * KCP + pcs : ABUF + pc4;
     }
     int aoff[NMT];
     int aoffy[SPLIT ? NMT : 1];                         // split mode: aoff = plane at +0/+16 for even taps, aoffy = the other plane
@@ -247,15 +273,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     for (int m = 0; m < NMT; ++m) {
         int r = 16 * m + (lane & 15);
         if (HM && r >= MT) r = 0;                       // dummy rows of the half-empty last M-tile
-        const int a = r / LM;
-        const int j = r - a * LM;
+        const int a = TMAP ? (lane & 15) % AG : r / LM;
+        const int j = TMAP ? RPT * m + (lane & 15) / AG : r - a * LM;
         if (SPLIT) {
             const int row = 2 + a * LP + STRIDE * j + p.off0;      // LDS row of tap 0
             const int blk = row * KCP * 4 + 32 * (lane >> 4);      // bytes: this lane's 8-channel block
             aoff[m] = blk + ((row & 1) ? 16 : 0);                  // hi plane on even taps, lo plane on odd taps
             aoffy[m] = blk + ((row & 1) ? 0 : 16);
         } else {
-            aoff[m] = ((2 + a * LP + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
+            aoff[m] = (a * ASTR + (2 + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
         }
     }
     v4f acc[NMT];
@@ -266,11 +292,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 #pragma unroll
         for (int i = 0; i < NPIECE; ++i) *reinterpret_cast<v4f*>(A + soff[i]) = st[i];
     };
-    for (int i = tid; i < 2 * (AG + 1) * 2 * (KCP / 4); i += NTHR) {
-        const int q = i % (KCP / 4), hr = (i / (KCP / 4)) % (2 * (AG + 1)), buf = i / ((KCP / 4) * 2 * (AG + 1));
-        const int g = hr >> 1;                          // gap index: 0 = leading rows, g>0 = behind agent g-1
-        const int row = (g == 0 ? 0 : g * LP) + (hr & 1);
-        *reinterpret_cast<v4f*>(lds + buf * ABUFP + row * KCP + q * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+    // zero the gaps: the two leading rows, and behind every agent its two halo rows (+ the AEX floats)
+    constexpr int GQ = (2 * KCP + AEX) / 4;             // 16-byte pieces per gap
+    for (int i = tid; i < 2 * (AG + 1) * GQ; i += NTHR) {
+        const int q = i % GQ, g = (i / GQ) % (AG + 1), buf = i / (GQ * (AG + 1));      // gap index: 0 = leading rows, g > 0 = behind agent g-1
+        if (g == 0 && q >= 2 * KCP / 4) continue;
+        const int at = g == 0 ? 0 : (g - 1) * ASTR + (2 + L_IN) * KCP;
+        *reinterpret_cast<v4f*>(lds + buf * ABUFP + at + q * 4) = v4f{0.f, 0.f, 0.f, 0.f};
     }
     store_chunk(0);
     __syncthreads();
@@ -476,7 +504,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ok[(16 * m + rb + r) * OP + col] = acc[m][r];
+            for (int r = 0; r < 4; ++r)      // accumulator row rb + r of M-tile m is GEMM row (agent, position) = ...
+                Ok[(TMAP ? ((rb + r) % AG) * LM + RPT * m + (rb + r) / AG : 16 * m + rb + r) * OP + col] = acc[m][r];
     }
     __syncthreads();
     STAMP(4);
@@ -599,7 +628,7 @@ static inline size_t lds_request(size_t need) { return g_lds_floor > need ? (g_l
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = (208 >> HM) / LM;
-    constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);   // image + dump row
+    constexpr int ABUF = conv_image_floats(L_IN, LM, STRIDE, KC, AIN, HM);   // image + dump row
     constexpr int OTILE = KS * 16 * (((208 >> HM) + 15) / 16) * (16 * NWN + 4);   // the epilogue's partial output tiles alias the A images
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
@@ -619,9 +648,10 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
 template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC, int NTAPS_A, int EPI_A, int NTAPS_B, int EPI_B, int AIN, int AOUT, int HM>
 static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_pad, hipStream_t s) {
     constexpr int AG = (208 >> HM) / LM;
-    constexpr int ABUF = (AG * (L_IN + 2) + 2 + 1) * (KC + 8);
+    constexpr int ABUF = conv_image_floats(L_IN, LM, 1, KC, AIN, HM);
     constexpr int OTILE = KS * 16 * (((208 >> HM) + 15) / 16) * (16 * NWN + 4);
     constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
+    static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT, HM>;
     static bool attr_done = false;
     if (!attr_done) {

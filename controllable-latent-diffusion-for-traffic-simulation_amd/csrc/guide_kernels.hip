@@ -745,6 +745,349 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
     }
 }
 
+// =============================================================================================
+// Two waves per SIMD: the same algorithm with EIGHT waves, wave w owning hidden units 8w..8w+7 of both layers.
+// =============================================================================================
+// With four waves (above) every SIMD holds one wave and half of a time step is dependency / LDS / barrier latency that
+// nothing covers (27k cycles per step for 13k cycles of MFMA issue).  Here every wave does half the work per step and two
+// of them share a SIMD, so one wave's cell update, exchange and barrier wait run under the other's MFMAs.
+//   forward : a wave's gate columns are two N-tiles, P = [i of its 8 units | f of its 8 units] and Q = [g | o]; in the result
+//             layout lane (n, rb) holds column n for agents 4rb..4rb+3, so lanes n < 8 hold (i, g) and lanes n >= 8 hold
+//             (f, o) of unit n & 7.  The two half-rows trade what the other needs with one DPP row rotation by 8 each
+//             (v_mov_dpp row_ror:8, VALU rate, no LDS) and split the four agents: lane n < 8 updates the cells of agents
+//             4rb, 4rb+1, lane n >= 8 those of agents 4rb+2, 4rb+3 -- half the transcendental work per lane as well.
+//   backward: the two transposed products of a layer share one N-tile: [W_hh1^T dG | W_ih1^T dG] for layer 1 and
+//             [W_hh0^T dG | W_ih0^T dG (4 latent channels) | 0] for layer 0, K = 256 gate columns each: lane n < 8 ends up with
+//             the recurrent gradient of unit n, lane n >= 8 with the gradient flowing down (layer 1) or with dL/dz_t, complete
+//             (layer 0; no cross-wave partial sums), and again one rotation by 8 hands each half what it needs.
+// Kept activations, the roll-out / loss scan (chain_grad) and the optimiser step are as in the four-wave kernel.
+namespace gm8 {
+constexpr int AG = 16, HS = 68, GS = 260;
+constexpr int ACTS = GT * 2 * 5 * 2 * 512;   // floats of kept activations per workgroup: [t][layer][i f g o c][q][thread]
+}  // namespace gm8
+
+__device__ __forceinline__ float xch8(float v) {      // the value lane ^ 8 holds (the other half of this 16-lane row)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+
+// [16 agents x 256 gate columns] x [256 x 16] on this wave's tile: row `src` of the gate-gradient tile (this lane's A row, k
+// offset 4 rb applied), B fragments tb[j][e] for gate column 16 j + 4 rb + e.  Two accumulators in turn (no back-to-back
+// dependent MFMAs); the A fragments are fetched four k-groups ahead and pinned there -- left alone the compiler hoists all
+// sixteen ds_read_b128 (64 VGPRs) to the top and the kernel, capped at 256 registers for two waves per SIMD, spills.
+__device__ __forceinline__ v4f tprod(const float* src, const float (&tb)[16][4]) {
+    v4f p0 = {0.f, 0.f, 0.f, 0.f}, p1 = {0.f, 0.f, 0.f, 0.f};
+    v4f cur[4], nxt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur[j] = *reinterpret_cast<const v4f*>(src + 16 * j);
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        if (blk < 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nxt[j] = *reinterpret_cast<const v4f*>(src + 16 * (4 * (blk + 1) + j));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j][0], tb[4 * blk + j][0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j][1], tb[4 * blk + j][1], p1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j][2], tb[4 * blk + j][2], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j][3], tb[4 * blk + j][3], p1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p0[r] += p1[r];
+    return p0;
+}
+
+__global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
+    using namespace gm8;
+    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
+    __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
+    __shared__ __attribute__((aligned(16))) float zin[AG][208];
+    __shared__ __attribute__((aligned(16))) float condm[AG][256];
+    __shared__ float actp[2][2][8][AG];      // [step parity][output][wave][agent]: per-wave partials of hid2act
+    __shared__ float act[2][GT][AG];         // (acceleration, yaw-rate), scaled
+    __shared__ float dact[AG][2][GT];
+    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
+    __shared__ float dz[AG][208];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, rb = lane >> 4;        // MFMA layouts: A lane = (row n, k rb); B lane = (col n, k rb); D lane = (col n, rows 4rb..4rb+3)
+    const int hi = n >> 3, m = n & 7;
+    const int u = 8 * wv + m;                       // this lane's hidden unit
+    const int ra = 4 * rb + 2 * hi;                 // the first of the two agents whose cells this lane updates
+    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
+
+    const int ngroups = (a.B + AG - 1) / AG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * AG;
+        // kept activations go through a buffer descriptor: the per-lane part of every address is ONE VGPR (4 tid) and the
+        // (step, layer, gate, row) part rides in the scalar offset -- no 64-bit vector address arithmetic per access
+        const __amdgpu_buffer_rsrc_t keep = __builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * ACTS, 0, ACTS * 4, 0x00020000);
+        const int kvo = tid * 4;
+        auto kput = [&](int slot, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), keep, kvo, slot * 2048, 0); };
+        auto kget = [&](int slot) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(keep, kvo, slot * 2048, 0)); };
+        auto agent = [&](int ag) { return (b0 + ag < a.B) ? b0 + ag : a.B - 1; };      // tail slots replay the last agent; never stored
+        for (int i = tid; i < AG * 256; i += 512) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
+        for (int i = tid; i < AG * 208; i += 512) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
+        __syncthreads();
+        for (int i = tid; i < AG * 64; i += 512) {      // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49)
+            const int ag = i >> 6, uu = i & 63;
+            float s = w.b_c2h[uu];
+            const float* wr = w.w_c2h + uu * 256;
+            for (int k = 0; k < 256; ++k) s = fmaf(condm[ag][k], wr[k], s);
+            hs[0][0][ag][uu] = s;
+            hs[1][0][ag][uu] = s;
+        }
+        float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
+        __syncthreads();
+        // The two accumulator tiles of a layer step -> the four gate pre-activations of this lane's two (agent, unit) cells.
+        // Lanes n < 8 hold P = i, Q = g, lanes n >= 8 hold P = f, Q = o (rows = agents 4rb..4rb+3); the lower half keeps
+        // rows 0, 1 and the upper half rows 2, 3.
+        auto gates = [&](const v4f& P, const v4f& Q, float (&ig)[2], float (&fg)[2], float (&gg)[2], float (&og)[2]) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float ownP = hi ? P[2 + q] : P[q], ownQ = hi ? Q[2 + q] : Q[q];
+                const float gotP = xch8(hi ? P[q] : P[2 + q]), gotQ = xch8(hi ? Q[q] : Q[2 + q]);     // what the other half holds for MY rows
+                ig[q] = hi ? gotP : ownP; fg[q] = hi ? ownP : gotP;
+                gg[q] = hi ? gotQ : ownQ; og[q] = hi ? ownQ : gotQ;
+            }
+        };
+        // ---------------- forward ----------------
+        {
+            // The weight pointers are made opaque INSIDE the group loop: the fragments are loop-invariant, and left visible the
+            // compiler hoists their address arithmetic (and, given registers, the loads) of BOTH phases out of the loop -- at the
+            // 256-register cap of two waves per SIMD that spills ~180 dwords and reloads them inside the time loop.
+            const float *p_hh0 = w.w_hh0, *p_ih1 = w.w_ih1, *p_hh1 = w.w_hh1, *p_ih0 = w.w_ih0, *p_b0 = w.b0, *p_b1 = w.b1;
+            asm volatile("" : "+v"(p_hh0), "+v"(p_ih1), "+v"(p_hh1), "+v"(p_ih0), "+v"(p_b0), "+v"(p_b1));
+            // B fragments of tile T (0: P, 1: Q): column n -> gate 2T + hi of unit 8 wv + m; k-step (j, e) -> k = 16 j + 4 rb + e
+            float f_hh0[2][4][4], f_ih1[2][4][4], f_hh1[2][4][4], f_ih0[2], fb0[2], fb1[2];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const int col = 64 * (2 * T + hi) + 8 * wv + m;
+                f_ih0[T] = p_ih0[col * 4 + rb];
+                fb0[T] = p_b0[col];
+                fb1[T] = p_b1[col];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const v4f x0 = *reinterpret_cast<const v4f*>(p_hh0 + col * 64 + 16 * jj + 4 * rb);
+                    const v4f x1 = *reinterpret_cast<const v4f*>(p_ih1 + col * 64 + 16 * jj + 4 * rb);
+                    const v4f x2 = *reinterpret_cast<const v4f*>(p_hh1 + col * 64 + 16 * jj + 4 * rb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { f_hh0[T][jj][e] = x0[e]; f_ih1[T][jj][e] = x1[e]; f_hh1[T][jj][e] = x2[e]; }
+                }
+            }
+            for (int t = 0; t < GT; ++t) {
+                const int pr = t & 1;
+                if (t > 0 && tid < 2 * AG) {      // actions of step t-1: the eight per-wave partials (written before the last barrier)
+                    const int o = tid >> 4, ag = tid & 15;
+                    float s = o ? bh2b : bh2a;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += actp[pr ^ 1][o][k][ag];
+                    act[o][t - 1][ag] = s;
+                }
+                // ---- layer 0: pre = b + x_t W_ih0^T + h0_{t-1} W_hh0^T ----
+                v4f P = {fb0[0], fb0[0], fb0[0], fb0[0]}, Q = {fb0[1], fb0[1], fb0[1], fb0[1]};
+                {
+                    const float xa = zin[n][4 * t + rb];
+                    P = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f_ih0[0], P, 0, 0, 0);
+                    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f_ih0[1], Q, 0, 0, 0);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        P = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_hh0[0][jj][e], P, 0, 0, 0);
+                        Q = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_hh0[1][jj][e], Q, 0, 0, 0);
+                    }
+                }
+                float ig[2], fg[2], gg[2], og[2];
+                gates(P, Q, ig, fg, gg, og);
+                int ks = (t * 2 + 0) * 10;          // slot of (step t, layer 0, gate 0, row 0); a slot = one float per thread
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float i_ = fsig(ig[q]), f_ = fsig(fg[q]), g_ = ftanh(gg[q]), o_ = fsig(og[q]);
+                    const float c = f_ * c0[q] + i_ * g_;
+                    c0[q] = c;
+                    hs[0][pr ^ 1][ra + q][u] = o_ * ftanh(c);
+                    kput(ks + 0 + q, i_); kput(ks + 2 + q, f_); kput(ks + 4 + q, g_); kput(ks + 6 + q, o_);
+                    kput(ks + 8 + q, c);
+                }
+                __syncthreads();
+                // ---- layer 1: pre = b + h0_t W_ih1^T + h1_{t-1} W_hh1^T ----
+                P = v4f{fb1[0], fb1[0], fb1[0], fb1[0]};
+                Q = v4f{fb1[1], fb1[1], fb1[1], fb1[1]};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][n][16 * jj + 4 * rb]);
+                    const v4f hb = *reinterpret_cast<const v4f*>(&hs[1][pr][n][16 * jj + 4 * rb]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        P = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[0][jj][e], P, 0, 0, 0);
+                        Q = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[1][jj][e], Q, 0, 0, 0);
+                        P = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[0][jj][e], P, 0, 0, 0);
+                        Q = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[1][jj][e], Q, 0, 0, 0);
+                    }
+                }
+                gates(P, Q, ig, fg, gg, og);
+                ks += 10;
+                float ap[2], aq[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float i_ = fsig(ig[q]), f_ = fsig(fg[q]), g_ = ftanh(gg[q]), o_ = fsig(og[q]);
+                    const float c = f_ * c1[q] + i_ * g_;
+                    c1[q] = c;
+                    const float hn = o_ * ftanh(c);
+                    hs[1][pr ^ 1][ra + q][u] = hn;
+                    kput(ks + 0 + q, i_); kput(ks + 2 + q, f_); kput(ks + 4 + q, g_); kput(ks + 6 + q, o_);
+                    kput(ks + 8 + q, c);
+                    ap[q] = hn * wa0;                       // hid2act: partials over this wave's 8 units
+                    aq[q] = hn * wa1;
+                }
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { ap[q] += __shfl_xor(ap[q], o); aq[q] += __shfl_xor(aq[q], o); }
+                if (m == 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { actp[pr][0][wv][ra + q] = ap[q]; actp[pr][1][wv][ra + q] = aq[q]; }
+                }
+                __syncthreads();
+            }
+        }
+        // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
+        if (tid < 2 * AG) {
+            const int o = tid >> 4, ag = tid & 15;
+            float s = o ? bh2b : bh2a;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += actp[(GT - 1) & 1][o][k][ag];
+            act[o][GT - 1][ag] = s;
+        }
+        __syncthreads();
+        if (tid < AG)
+            chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
+        __syncthreads();
+        // ---------------- backward through time ----------------
+        {
+            // B fragments of the transposed products, k-step (j, e) -> gate column col = 16 j + 4 rb + e:
+            //   layer 1 tile: column n < 8 -> W_hh1[col][unit 8 wv + n], n >= 8 -> W_ih1[col][unit 8 wv + n - 8]
+            //   layer 0 tile: column n < 8 -> W_hh0[col][unit 8 wv + n], 8 <= n < 12 -> W_ih0[col][latent channel n - 8], else 0
+            // One base pointer per tile, picked per lane ONCE (a per-element pointer select makes the compiler branch around
+            // every load and wait for each), opaque inside the group loop as in the forward phase; every lane loads, lanes
+            // 12..15 of the layer-0 tile drop what they read.
+            const float* p1 = (hi ? w.w_ih1 : w.w_hh1) + 4 * rb * 64 + 8 * wv + m;
+            const float* p0 = hi ? w.w_ih0 + 4 * rb * 4 + (m & 3) : w.w_hh0 + 4 * rb * 64 + 8 * wv + m;
+            asm volatile("" : "+v"(p1), "+v"(p0));
+            const int st0 = hi ? 4 : 64;                 // floats per gate column in the layer-0 source
+            const bool dead = hi && m >= 4;
+            float t1[16][4], t0[16][4];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t1[jj][e] = p1[(16 * jj + e) * 64];
+                    const float v = p0[(16 * jj + e) * st0];
+                    t0[jj][e] = dead ? 0.f : v;
+                }
+            float rec1[2] = {0.f, 0.f}, rec0[2] = {0.f, 0.f};
+            float dc1n[2] = {0.f, 0.f}, dc0n[2] = {0.f, 0.f};
+            // kept activations of one (step, layer): i f g o c of this lane's two cells + the previous cell state; fetched from
+            // the L2-resident scratch one phase ahead, in flight under the MFMA block that precedes their use
+            float kv1[6][2], kv0[6][2];
+            auto fetch = [&](float (&kv)[6][2], int t, int layer) {
+                const int ks = (t * 2 + layer) * 10;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) kv[k][q] = kget(ks + 2 * k + q);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) kv[5][q] = t > 0 ? kget(ks - 20 + 8 + q) : 0.f;      // the cell state of step t-1, same layer
+            };
+            fetch(kv1, GT - 1, 1);
+            for (int t = GT - 1; t >= 0; --t) {
+                // ---- layer 1 gate gradients -> LDS ----
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float i_ = kv1[0][q], f_ = kv1[1][q], g_ = kv1[2][q], o_ = kv1[3][q], c = kv1[4][q], cp = kv1[5][q];
+                    const float tc = ftanh(c);
+                    const float dh = wa0 * dact[ra + q][0][t] + wa1 * dact[ra + q][1][t] + rec1[q];
+                    const float dc = dh * o_ * (1.f - tc * tc) + dc1n[q];
+                    float* row = &dG[0][ra + q][u];
+                    row[0] = dc * g_ * i_ * (1.f - i_);
+                    row[64] = dc * cp * f_ * (1.f - f_);
+                    row[128] = dc * i_ * (1.f - g_ * g_);
+                    row[192] = dh * tc * o_ * (1.f - o_);
+                    dc1n[q] = dc * f_;
+                }
+                __syncthreads();
+                fetch(kv0, t, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                v4f pa = tprod(&dG[0][n][4 * rb], t1);
+                // lanes n < 8: pa = recurrent gradient (-> rec1 of step t-1); lanes n >= 8: pa = dL/dh0_t from layer 1
+                float down[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float got = xch8(hi ? pa[q] : pa[2 + q]);
+                    rec1[q] = hi ? got : pa[q];
+                    down[q] = hi ? pa[2 + q] : got;
+                }
+                // ---- layer 0 gate gradients -> LDS ----
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float i_ = kv0[0][q], f_ = kv0[1][q], g_ = kv0[2][q], o_ = kv0[3][q], c = kv0[4][q], cp = kv0[5][q];
+                    const float tc = ftanh(c);
+                    const float dh = down[q] + rec0[q];
+                    const float dc = dh * o_ * (1.f - tc * tc) + dc0n[q];
+                    float* row = &dG[1][ra + q][u];
+                    row[0] = dc * g_ * i_ * (1.f - i_);
+                    row[64] = dc * cp * f_ * (1.f - f_);
+                    row[128] = dc * i_ * (1.f - g_ * g_);
+                    row[192] = dh * tc * o_ * (1.f - o_);
+                    dc0n[q] = dc * f_;
+                }
+                __syncthreads();
+                if (t > 0) fetch(kv1, t - 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                v4f pc = tprod(&dG[1][n][4 * rb], t0);
+                // lanes n < 8: pc = recurrent gradient (-> rec0 of step t-1); lanes 8 <= n < 12: pc = dL/dz_t, channel n - 8, complete
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float got = xch8(pc[2 + q]);
+                    rec0[q] = hi ? got : pc[q];
+                }
+                if (wv == 0 && hi && m < 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz[4 * rb + r][4 * t + m] = pc[r];
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
+        for (int i = tid; i < AG * 208; i += 512) {
+            const int ag = i / 208, r = i % 208, b = b0 + ag;
+            if (b >= a.B) continue;
+            const float g = dz[ag][r];
+            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
+            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
+            const float mu = zin[ag][r] + delta;
+            if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
+            if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
+            if (a.x_out) {
+                float zz = 0.f;
+                if (a.sigma != 0.f) zz = a.z ? a.z[(size_t)b * 208 + r] : normal4(a.seed, a.step_salt, (unsigned)(b * 52 + (r >> 2)))[r & 3];
+                const float xn = mu + a.sigma * zz;
+                a.x_out[(size_t)b * 208 + r] = xn;
+                if (a.x_out2) a.x_out2[(size_t)b * 208 + r] = xn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int guide_mfma_grid(int B) {
     const int groups = (B + gm::AG - 1) / gm::AG;
     return groups < 256 ? groups : 256;
@@ -753,17 +1096,21 @@ static int guide_mfma_grid(int B) {
 // (32 workgroups) up it is faster than the 2-agent VALU kernel (tests force either form through cld_debug_force_kernel).
 static bool use_mfma_guide(int B, int form) {
     if (form == FORM_VALU) return false;
-    if (form == FORM_MFMA) return true;
+    if (form == FORM_MFMA || form == FORM_MFMA_4WAVE) return true;
     return B >= 512;
 }
 size_t guide_scratch_floats(int B) {
     const size_t valu = (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS);
+    static_assert(gm::ACTS == gm8::ACTS, "both MFMA formulations keep the same number of activations per workgroup");
     const size_t mfma = (size_t)guide_mfma_grid(B) * gm::ACTS;
     return valu > mfma ? valu : mfma;
 }
 
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
-    if (use_mfma_guide(a.B, form)) hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a);
+    if (use_mfma_guide(a.B, form)) {
+        if (form == FORM_MFMA_4WAVE) hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a);
+        else hipLaunchKernelGGL(guide_mfma8_kernel, dim3(guide_mfma_grid(a.B)), dim3(512), 0, s, w, d, a);
+    }
     else hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
     return hipGetLastError();
 }

@@ -1,0 +1,38 @@
+"""Per-launch breakdown of one U-Net evaluation from a rocprofv3 kernel trace of scripts/one_unet.py:
+    python3 scripts/unet_breakdown.py <t_kernel_trace.csv> <agents>
+Prints, for every launch of the LAST evaluations in the trace (median over them), the kernel instance, its duration, its
+algorithmic FLOP (2 * rows * K * N of the layers it computes, SURVEY 8(a) layer table) and the fp32-MFMA rate it reaches."""
+import csv, statistics, sys
+
+# MAC per agent of every launch of run_unet (csrc/cld_api.hip), in launch order; pairs are one launch
+L = [("b0.c0+res 4->64@52", 66560 + 13312), ("b0.c1 64->64@52", 1064960), ("b1.c0", 1064960), ("b1.c1", 1064960),
+     ("down0 k3s2", 319488), ("b2.c0+res 64->128@26", 1064960 + 212992), ("b2.c1 128->128@26", 2129920), ("b3.c0", 2129920),
+     ("b3.c1", 2129920), ("down1 k3s2", 638976), ("b4.c0+res 128->256@13", 2129920 + 425984), ("b4.c1 256->256@13", 4259840),
+     ("b5.c0", 4259840), ("b5.c1", 4259840), ("b6.c0", 4259840), ("b6.c1", 4259840), ("b7.c0", 4259840), ("b7.c1", 4259840),
+     ("b8.c0+res 512->128@13", 4259840 + 851968), ("b8.c1 128->128@13", 1064960), ("b9.c0", 1064960), ("b9.c1", 1064960),
+     ("up0 convT 128@13->26", 2 * 425984), ("b10.c0+res 256->64@26", 2129920 + 425984), ("b10.c1 64->64@26", 532480),
+     ("b11.c0", 532480), ("b11.c1", 532480), ("up1 convT 64@26->52", 2 * 212992), ("final_conv.0 64->64@52", 1064960),
+     ("head 1x1 64->4 + update", 13312)]
+path, B = sys.argv[1], int(sys.argv[2])
+rows = [r for r in csv.DictReader(open(path)) if "cld::" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+names = [r["Kernel_Name"] for r in rows]
+# an evaluation = a run of conv launches closed by head_kernel
+ends = [i for i, n in enumerate(names) if "head_kernel" in n]
+evals = []
+for e in ends:
+    s = e - (len(L) - 1)
+    if s >= 0 and all(("conv_block_kernel" in n or "conv_pair_kernel" in n) for n in names[s:e]):
+        evals.append(rows[s:e + 1])
+evals = evals[-8:]
+assert evals, "no complete U-Net evaluation in the trace"
+tot_t = tot_f = 0.0
+print(f"{len(evals)} evaluations, {B} agents; peak 157.3 TFLOP/s")
+for i, (tag, mac) in enumerate(L):
+    d = statistics.median(int(ev[i]["End_Timestamp"]) - int(ev[i]["Start_Timestamp"]) for ev in evals) / 1e3
+    fl = 2.0 * mac * B
+    k = evals[-1][i]["Kernel_Name"].replace("void cld::", "").replace("(cld::ConvArgs)", "").replace("(cld::ConvPairArgs)", "")
+    print(f"{i:2d} {tag:28s} {d:8.1f} us {fl/1e9:8.3f} GFLOP {fl/d/1e6:7.1f} TF/s {fl/d/1e6/157.3*100:5.1f}%  ideal {fl/157.3e6:6.1f} us  {k[:70]}")
+    tot_t += d; tot_f += fl
+wall = statistics.median(int(ev[-1]["End_Timestamp"]) - int(ev[0]["Start_Timestamp"]) for ev in evals) / 1e3
+print(f"sum of kernels {tot_t:.1f} us, first start -> last end {wall:.1f} us, {tot_f/1e9:.1f} GFLOP, ideal {tot_f/157.3e6:.1f} us -> {tot_f/wall/1e6/157.3*100:.1f}% of peak")

@@ -832,15 +832,16 @@ def test_encode_mfma_kernel_vs_oracle_and_valu():
 @pytest.mark.parametrize("n", [10, 50, 100])
 def test_schedule_buffers_golden(golden, n):
     """a-1 directly: the three buffers the sampler reads (dm_model.py:29-56), rebuilt in C++ by cld_create and returned by
-    cld_get_schedule, against the reference's own buffers: <= 1 ulp (the C++ libm and numpy / torch may round cos / log /
-    sqrt differently in the last bit)."""
+    cld_get_schedule, against the reference's own buffers: <= 1 ulp (in fact bit-identical except one x_t_cof entry at n = 50,
+    where torch's vectorised sqrt and the correctly rounded one differ in the last bit).  What it takes: the cumulative product
+    accumulated in double like torch.cumprod does on the CPU, and the logarithm taken in double."""
     from cld_amd.engine import Engine
     _, g = golden(f"schedule_n{n}")
     e = Engine(n_timesteps=n, device="cuda:0")
-    for name in ("x_t_cof", "noise_cof", "posterior_log_variance_clipped"):
+    for name, ulps in (("x_t_cof", 1), ("noise_cof", 1), ("posterior_log_variance_clipped", 1)):
         got, ref = getattr(e, name), g[name]
         assert got.dtype == np.float32 and got.shape == ref.shape
-        assert np.all(np.abs(got - ref) <= np.spacing(np.abs(ref))), (name, np.abs(got - ref).max())
+        assert np.all(np.abs(got - ref) <= ulps * np.spacing(np.abs(ref))), (name, np.abs(got - ref).max())
     assert e.posterior_log_variance_clipped[0] == np.float32(np.log(np.float32(1e-20)))       # the 1e-20 clamp -> sigma_0 = 1e-10
 
 
@@ -986,18 +987,18 @@ def test_guidance_on_the_output_step_vs_oracle(eng10):
     tgt = torch.from_numpy(synth.uniform(17, "tgt", (B, 52), 0.0, 12.0))
     nz = synth.make_noise(B, n, 6)
     xT, noise = torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"])
-    gd = {"curr_states": cs, "target_speed": tgt, "lr": 0.3, "optimizer": "adam", "output": {"lr": 0.2, "optimizer": "sgd", "perturb_th": 1.0}}
+    gd = {"curr_states": cs, "target_speed": tgt, "lr": 0.3, "optimizer": "adam", "output": {"lr": 0.2, "optimizer": "adam", "perturb_th": 1.0}}
     x0, _, _ = eng10.sample(xT, cond, noise=noise, guidance=gd)
     torch.set_num_threads(8)
     w, wd = O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), O.to_torch(synth.make_decoder_weights(0))
-    ref = O.sample_guided(w, wd, O.schedule(n), xT, noise, cond, cs, tgt, lr=0.3, optimizer="adam", output={"lr": 0.2, "optimizer": "sgd"})["pred_traj"]
+    ref = O.sample_guided(w, wd, O.schedule(n), xT, noise, cond, cs, tgt, lr=0.3, optimizer="adam", output={"lr": 0.2, "optimizer": "adam"})["pred_traj"]
     plain = O.sample_guided(w, wd, O.schedule(n), xT, noise, cond, cs, tgt, lr=0.3, optimizer="adam")["pred_traj"]
     scale = float(ref.abs().max())
     assert float((x0.cpu() - ref).abs().max()) <= 1e-3 * scale
-    assert float((plain - ref).abs().max()) > 1e-4 * scale                 # the output step did something
+    assert float((plain - ref).abs().max()) > 0.15                         # the output step did something: Adam's first step is lr = 0.2 per element
     only, _, _ = eng10.sample(xT, cond, noise=noise, guidance=dict(gd, intermediate=False))
     base, _, _ = eng10.sample(xT, cond, noise=noise)
-    mean_g = eng10.guidance_step(base, cond, {"curr_states": cs, "target_speed": tgt, "lr": 0.2, "optimizer": "sgd"}, sigma=0.0)
+    mean_g = eng10.guidance_step(base, cond, {"curr_states": cs, "target_speed": tgt, "lr": 0.2, "optimizer": "adam"}, sigma=0.0)
     assert float((only - mean_g).abs().max()) <= 1e-5 * float(base.abs().max())
 
 
