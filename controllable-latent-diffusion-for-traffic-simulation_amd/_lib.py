@@ -86,6 +86,7 @@ SIGNATURES = {
     "cld_debug_lds_floor": (C.c_int, [_P, C.c_size_t]),
     "cld_debug_force_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "cld_debug_stamps": (C.c_int, [_P, _P, C.c_int32]),
+    "cld_debug_guide_stamps": (C.c_int, [_P]),
     "cld_get_precision": (C.c_int, [_P]),
     "cld_version": (C.c_char_p, []),
 }

@@ -61,7 +61,7 @@ struct cld_handle_s {
     // device-side model
     ResBlock blocks[12];
     ConvLayer down[2], upT[2][2], final_cb;
-    float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr;
+    float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr, *res4_w = nullptr, *res4_b = nullptr;
     DecoderWeights dec{};
     EncoderWeights enc{};
     bool has_encoder = false;
@@ -231,6 +231,22 @@ std::vector<float> pack_conv_weights(F&& wget, int c_out, int cin_virtual, int n
                 for (int lane = 0; lane < 64; ++lane)
                     for (int s = 0; s < 4; ++s)
                         out[o++] = wget(16 * nt + (lane & 15), 16 * kgg + 4 * (lane >> 4) + s, t);
+    return out;
+}
+
+// The latent's convolution (4 -> 64 channels, k = 5): K folded over (tap, channel).  Per N tile and lane (n, kk) eight floats:
+// [0..3] = W[co][channel s][tap kk], s = 0..3 (the B values of the four MFMAs that walk taps 0..3) and [4] = W[co][channel kk][tap 4].
+template <class F>
+std::vector<float> pack_latent_conv_weights(F&& wget, int c_out) {
+    const int ntn = c_out / 16;
+    std::vector<float> out((size_t)ntn * 64 * 8, 0.f);
+    for (int nt = 0; nt < ntn; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+            float* o = &out[((size_t)nt * 64 + lane) * 8];
+            const int co = 16 * nt + (lane & 15), kk = lane >> 4;
+            for (int s = 0; s < 4; ++s) o[s] = wget(co, s, kk);
+            o[4] = wget(co, kk, 4);
+        }
     return out;
 }
 
@@ -408,9 +424,12 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
     return e != hipSuccess ? e : launch_maybe_timed(h, lb, gb, ab, b_pad, s);
 }
 
+hipError_t run_args(cld_handle h, const ConvLayer& l, ConvArgs a, int b_pad, hipStream_t s);
 hipError_t run_conv(cld_handle h, const ConvLayer& l, const float* x1, const float* x2, float* y, const float* res,
                     const float* cb, const float* tb_row, int b_pad, hipStream_t s) {
-    ConvArgs a = make_args(h, l, x1, x2, y, res, cb, tb_row);
+    return run_args(h, l, make_args(h, l, x1, x2, y, res, cb, tb_row), b_pad, s);
+}
+hipError_t run_args(cld_handle h, const ConvLayer& l, ConvArgs a, int b_pad, hipStream_t s) {
 #ifdef CLD_EXPERIMENTS
     static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;
     if (h->launch_counter >= stop_after) return hipSuccess;
@@ -446,7 +465,13 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         return hipSuccess;
     };
 #define RB(...) do { e = resblock(__VA_ARGS__); if (e != hipSuccess) return e; } while (0)
-    RB(h->blocks[0], x, nullptr, b[2]);
+    {   // block 0: conv(4 -> 64) | conv(64 -> 64) + residual_conv(x), the 1x1 projection of the latent evaluated in the epilogue
+        RC(h->blocks[0].c0, x, nullptr, b[1], nullptr);
+        ConvArgs a1 = make_args(h, h->blocks[0].c1, b[1], nullptr, b[2], nullptr, w.cb, tbr);
+        a1.res4_x = x; a1.res4_w = h->res4_w; a1.res4_b = h->res4_b;
+        e = run_args(h, h->blocks[0].c1, a1, b_pad, s);
+        if (e != hipSuccess) return e;
+    }
     RB(h->blocks[1], b[2], nullptr, b[3]);
     RC(h->down[0], b[3], nullptr, b[6], nullptr);
     RB(h->blocks[2], b[6], nullptr, b[2]);
@@ -530,6 +555,12 @@ int cld_debug_stamps(cld_handle h, void* buf, int32_t layer) {
     if (!h) return CLD_ERR_ARG;
     h->stamp_buf = static_cast<unsigned long long*>(buf);
     h->stamp_layer = layer;
+    return CLD_OK;
+}
+
+int cld_debug_guide_stamps(void* out_host) {
+    if (!out_host) return CLD_ERR_ARG;
+    read_guide_stamps(static_cast<unsigned long long*>(out_host));
     return CLD_OK;
 }
 
@@ -645,8 +676,9 @@ int cld_finalize(cld_handle h, void* stream) {
             return transposed ? W[((size_t)ci * c_out + co) * kw + k]     // ConvTranspose1d [C_in, C_out, k]
                               : W[((size_t)co * cin_real + ci) * kw + k]; // Conv1d [C_out, C_in, k]
         };
-        std::vector<float> packed = ain ? pack_conv_weights_split(wget, c_out, c1_pad + c2, ntaps)
-                                        : pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
+        std::vector<float> packed = c1_real < 32 ? pack_latent_conv_weights(wget, c_out)
+                                    : ain       ? pack_conv_weights_split(wget, c_out, c1_pad + c2, ntaps)
+                                                : pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
         UP(l.wfrag, packed);
         UP(l.bias, *getw(h, wname + ".bias"));
         if (epi == EPI_GN_MISH) {
@@ -680,10 +712,14 @@ int cld_finalize(cld_handle h, void* stream) {
         rb.c0.cb_off = cb_off;
         if ((rc = make_conv(rb.c1, p + ".blocks.1.block.0", bd.cout, bd.cout, 0, bd.L, bd.L, 1, 5, k5, false, -2, 0, 1,
                             bd.L, EPI_GN_MISH, p + ".blocks.1.block.2")) != CLD_OK) return rc;
-        rb.has_res = bd.cin != bd.cout;
+        rb.has_res = bd.cin != bd.cout && !latent_in;
         if (rb.has_res)
             if ((rc = make_conv(rb.res, p + ".residual_conv", bd.cout, c1, c2, bd.L, bd.L, 1, 1, k1, false, 0, 0, 1, bd.L,
                                 EPI_BIAS, "", latent_in)) != CLD_OK) return rc;
+        if (latent_in) {      // the first block's 1x1 residual projection of the 4-channel latent runs inside its second conv's epilogue
+            UP(h->res4_w, *getw(h, p + ".residual_conv.weight"));      // [64, 4, 1]
+            UP(h->res4_b, *getw(h, p + ".residual_conv.bias"));
+        }
         cb_off += bd.cout;
     }
     if ((rc = make_conv(h->down[0], "model.downs.0.2.conv", 64, 64, 0, 52, 26, 2, 3, k3, false, -1, 0, 1, 26, EPI_BIAS, ""))) return rc;
@@ -786,6 +822,27 @@ int cld_finalize(cld_handle h, void* stream) {
         UP(tmp, *getw(h, "lstm_dec.cond2hidden.bias")); h->dec.b_c2h = tmp;
         UP(tmp, *getw(h, "lstm_dec.hid2act.weight")); h->dec.w_h2a = tmp;
         UP(tmp, *getw(h, "lstm_dec.hid2act.bias")); h->dec.b_h2a = tmp;
+        {   // B fragments of the backward products of guide_mfma8_kernel (guide_kernels.hip): wave wv owns units 8 wv .. 8 wv + 7;
+            // tile 0 = layer 1: column n < 8 -> W_hh1[col][8 wv + n], n >= 8 -> W_ih1[col][8 wv + n - 8];
+            // tile 1 = layer 0: column n < 8 -> W_hh0[col][8 wv + n], 8 <= n < 12 -> W_ih0[col][n - 8], else 0;
+            // k-step (j, e) of lane (n, rb) is gate column col = 16 j + 4 rb + e.  One coalesced float4 per (tile, j) and lane.
+            const std::vector<float>&hh1 = *getw(h, "lstm_dec.lstm.weight_hh_l1"), &ih1 = *getw(h, "lstm_dec.lstm.weight_ih_l1"),
+                                    &hh0 = *getw(h, "lstm_dec.lstm.weight_hh_l0"), &ih0 = *getw(h, "lstm_dec.lstm.weight_ih_l0");
+            std::vector<float> g((size_t)8 * 2 * 16 * 64 * 4);
+            size_t o = 0;
+            for (int wv = 0; wv < 8; ++wv)
+                for (int tile = 0; tile < 2; ++tile)
+                    for (int j = 0; j < 16; ++j)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int n = lane & 15, rb = lane >> 4, hi = n >> 3, m = n & 7, col = 16 * j + 4 * rb + e;
+                                float v;
+                                if (tile == 0) v = (hi ? ih1 : hh1)[(size_t)col * 64 + 8 * wv + m];
+                                else v = hi ? (m < 4 ? ih0[(size_t)col * 4 + m] : 0.f) : hh0[(size_t)col * 64 + 8 * wv + m];
+                                g[o++] = v;
+                            }
+            UP(tmp, g); h->dec.gfrag = tmp;
+        }
     }
     // ---- encoder (optional) ---------------------------------------------------------------
     h->has_encoder = true;

@@ -37,6 +37,10 @@ struct ConvArgs {
     int cb_stride;
     const float* tbias;   // per-step vector added after Mish: tbias[n] (or null)
     const float* res;     // residual tensor, same layout as y (or null)
+    // residual computed in the epilogue from a 4-channel tensor instead (the first block: residual_conv of the latent):
+    const float* res4_x;  // [B_pad, ly, 4] (or null)
+    const float* res4_w;  // [c_out][4] Conv1d(4 -> c_out, k = 1) weight
+    const float* res4_b;  // [c_out]
     float* y;             // output [B_pad, ly, c_out]
     int c_out;
     int ly;               // rows per agent of the OUTPUT tensor
@@ -118,6 +122,8 @@ struct DecoderWeights {   // device pointers, reference layouts
     const float *w_ih1, *w_hh1, *b1;   // [256,64] [256,64] [256]
     const float *w_c2h, *b_c2h;        // [64,256] [64]
     const float *w_h2a, *b_h2a;        // [2,64] [2]
+    // re-layouts made at cld_finalize for the MFMA guidance kernel (null when the decoder is absent):
+    const float* gfrag;                // [wave 8][tile 2][k-group 16][lane 64][4]: B fragments of the transposed (backward) products
 };
 struct DynParams {
     float dt, acc_lo, acc_hi, v_lo, v_hi, max_steer, max_yawvel;
@@ -204,6 +210,7 @@ struct GuideArgs {
     unsigned long long seed, step_salt;
 };
 size_t guide_scratch_floats(int B);
+void read_guide_stamps(unsigned long long* out);     // -DCLD_STAMPS builds: 8 shader-clock stamps per workgroup (256 workgroups); else a no-op
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form = FORM_AUTO);
 
 // per-agent values of the built-in guidance losses on a decoded trajectory (include/cld.h cld_guidance_losses); uses the loss

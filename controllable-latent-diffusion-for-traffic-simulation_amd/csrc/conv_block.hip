@@ -48,10 +48,12 @@ constexpr int conv_image_floats(int l_in, int lm, int stride, int kc, int ain, i
 
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)) == x * n / (n + 2), n = e^x (e^x + 2): one exp, no cancellation.
-    // v_exp_f32 / v_rcp_f32 are 1-ulp instructions: relative error ~2e-7, far inside the parity bar.
+    // v_exp_f32 / v_rcp_f32 are 1-ulp instructions: relative error ~2e-7, far inside the parity bar.  The reciprocal is the
+    // bare v_rcp_f32 (__builtin_amdgcn_rcpf): __frcp_rn / 1.0f / x compile to the ten-instruction correctly-rounded division
+    // (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup), which doubled the VALU work of every epilogue until round 2.
     const float e = __expf(fminf(x, 30.0f));
     const float n = e * (e + 2.0f);
-    return x * n * __frcp_rn(n + 2.0f);
+    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
 #ifdef CLD_STAMPS
@@ -112,7 +114,9 @@ __device__ __forceinline__ void s22_encode(const float (&v)[4], h4& hi, h4& lo) 
     }
 }
 
-// PADC: the input has fewer real channels than one K chunk (the 4-channel latent): zero-fill the rest.
+// PADC: the input is the 4-channel latent (first conv of the U-Net, k = 5).  Its K is folded over (tap, channel): 20 values =
+// five MFMA k-steps per M-tile instead of the 40 a zero-padded 32-channel chunk walked tap by tap would take -- lane (row, kk)
+// reads the four channels of row + kk (taps 0..3, one ds_read_b128, four MFMAs) and channel kk of row + 4 (tap 4, one MFMA).
 // AIN / AOUT: activation format of the input / of the output and residual (0 = fp32, 1 = S22).  AIN = 1 selects the
 // split-precision loop: products hi*hi + hi*lo + lo*hi on the fp16 MFMA (weights pre-split and pre-scaled on the
 // host), fp32 accumulation -- measured indistinguishable from the exact-fp32 loop on this network
@@ -225,7 +229,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     // B fragments: slab (16-channel group kgg, tap t) holds [ntn][64 lanes][4]; see pack_conv_weights
     const int ngrp = (p.c1_pad + p.c2) >> 4;
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.wfrag), 0, ngrp * NTAPS * ntn * 1024, 0x00020000);
+        const_cast<float*>(p.wfrag), 0, PADC ? ntn * 2048 : ngrp * NTAPS * ntn * 1024, 0x00020000);
     const int wlane = lane * 16;
     auto wload = [&](int c, int it) {                   // `it` may run past the chunk
         const int cc = c + it / NIT, ii = it % NIT;
@@ -246,8 +250,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     //      (divisions by the row counts), the accumulator clear and the halo zeroing run under their latency ----
     load_chunk(0);
     // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them
-    v4f bq0 = SPLIT ? wload_hi(0, 0) : wload(0, 0);
-    v4f bq1 = (1 / NIT < nchunk) ? (SPLIT ? wload_hi(0, 1) : wload(0, 1)) : bq0;
+    // (PADC: the whole layer is two fragments per N tile -- taps 0..3 x 4 channels, and tap 4; see pack_latent_conv_weights)
+    v4f bq0 = PADC ? buf_load16(rsw, lane * 32, ntile_g * 2048) : (SPLIT ? wload_hi(0, 0) : wload(0, 0));
+    v4f bq1 = PADC ? buf_load16(rsw, lane * 32 + 16, ntile_g * 2048)
+                   : ((1 / NIT < nchunk) ? (SPLIT ? wload_hi(0, 1) : wload(0, 1)) : bq0);
     v4f bl0 = bq0, bl1 = bq0;                           // lo planes of the two queued weight fragments (split mode)
     if (SPLIT) {
         bl0 = wload_lo(0, 0);
@@ -281,7 +287,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
             aoff[m] = blk + ((row & 1) ? 16 : 0);                  // hi plane on even taps, lo plane on odd taps
             aoffy[m] = blk + ((row & 1) ? 0 : 16);
         } else {
-            aoff[m] = (a * ASTR + (2 + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
+            aoff[m] = PADC ? (a * ASTR + (2 + j + p.off0 + (lane >> 4)) * KCP) * 4       // channels 0..3 of the row of tap kk = lane >> 4
+                           : (a * ASTR + (2 + STRIDE * j + p.off0) * KCP + 4 * (lane >> 4) + 16 * ks) * 4;
         }
     }
     v4f acc[NMT];
@@ -318,7 +325,24 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     constexpr int CUNR = 2;     // chunk pairs: image index and fragment-buffer parity are compile-time, so every
                                 // LDS fragment address is one loop-invariant VGPR + an immediate offset
     const char* ldsb = reinterpret_cast<const char*>(lds);
-    if constexpr (SPLIT) {
+    if constexpr (PADC) {
+        static_assert(NTAPS == 5 && !SPLIT && STRIDE == 1 && KS <= 2, "the folded loop is the latent's k = 5 convolution");
+        // with a K split the first rank takes taps 0..3 and the last rank tap 4 (KS = 1: one wave does both)
+        if (ks == 0) {
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const v4f a4 = *reinterpret_cast<const v4f*>(ldsb + aoff[m]);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sidx], bq0[sidx], acc[m], 0, 0, 0);
+            }
+        }
+        if (ks == KS - 1) {
+            const int t4 = ((4 - (lane >> 4)) * KCP + (lane >> 4)) * 4;      // from (row + kk, channel 0) to (row + 4, channel kk)
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(ldsb + aoff[m] + t4), bq1[0], acc[m], 0, 0, 0);
+        }
+    } else if constexpr (SPLIT) {
         // Split-precision loop: one iteration = one tap of a 32-channel chunk; per M-tile two ds_read_b128 (hi / lo
         // plane, for the NEXT iteration) and three fp16 MFMAs (K = 32).  Same chunk pipeline as the fp32 loop.
         v4f ah[2][NMT], al[2][NMT];
@@ -464,7 +488,22 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     // S22 tensors: the 4 channels of a vector sit at (fp32 byte offset) - 2 * (n & 7) in the hi plane, + 16 in the lo plane
     const int s22_adj = AOUT == 1 ? -2 * (n & 7) : 0;
     vec_t rv[NV];
-    if (p.res) {
+    if (p.res4_x) {
+        // the first block's residual: residual_conv = Conv1d(4 -> 64, k = 1) of the block input (temporal.py:32-34), the latent
+        // itself -- 16 FMAs per output vector here instead of a [B,52,64] tensor written and read back through HBM
+        v4f w4[VW];
+#pragma unroll
+        for (int e = 0; e < VW; ++e) w4[e] = *reinterpret_cast<const v4f*>(p.res4_w + (size_t)(n + e) * 4);
+        const vec_t b4 = *reinterpret_cast<const vec_t*>(p.res4_b + n);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int j = (i < NV - 1 || last_ok) ? RPI * i + jr : jr;
+            const v4f x4 = *reinterpret_cast<const v4f*>(p.res4_x + ((size_t)(b0 + a) * LM + j) * 4);
+#pragma unroll
+            for (int e = 0; e < VW; ++e)
+                vset<VW>(rv[i], e, vget<VW>(b4, e) + w4[e][0] * x4[0] + w4[e][1] * x4[1] + w4[e][2] * x4[2] + w4[e][3] * x4[3]);
+        }
+    } else if (p.res) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if (!(i < NV - 1 || last_ok)) { rv[i] = vec_t{0.f, 0.f, 0.f, 0.f}; continue; }
@@ -570,7 +609,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     for (int i = 0; i < NV; ++i) {
         vec_t o;
 #pragma unroll
-        for (int e = 0; e < VW; ++e) vset<VW>(o, e, p.res ? v[i][e] + vget<VW>(rv[i], e) : v[i][e]);
+        for (int e = 0; e < VW; ++e) vset<VW>(o, e, (p.res || p.res4_x) ? v[i][e] + vget<VW>(rv[i], e) : v[i][e]);
         if (i < NV - 1 || last_ok) {
             if (AOUT == 1) {
                 float ov[4];
@@ -668,10 +707,6 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
 
 // pairs: (L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT), stride 1 on both sides
 #define CLD_PAIR_INSTANCES(X)                                         \
-    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
-    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
-    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
-    X(52, 52, 32, 2, 2, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
     X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
@@ -696,7 +731,6 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 2) \
-    X(52, 52, 32, 4, 1, 8, 1, 1, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 1, 0) \
     X(26, 26, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
     X(13, 13, 64, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
     X(13, 13, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
@@ -741,10 +775,6 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 1) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 2) \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 0, 0) \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 0) \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 1) \
-    X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 1, 0, 0, 2) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 1) \
@@ -803,7 +833,6 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 1) \
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 2) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1, 0) \
-    X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 1, 0, 1, 0) \
     X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1, 0) \
     X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0, 0) \
     X(26, 26, 1, 5, 64, 4, 1, EPI_GN_MISH, 16, 1, 0, 1, 1, 0) \

@@ -464,8 +464,8 @@ constexpr int GS = 260;                 // LDS row stride of the gate-gradient t
 constexpr int ACTS = GT * 2 * 5 * 4 * 256;   // floats of kept activations per workgroup: [t][layer][i f g o c][r][thread]
 }  // namespace gm
 
-__device__ __forceinline__ float fsig(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ftanh(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
     using namespace gm;
@@ -766,6 +766,12 @@ constexpr int AG = 16, HS = 68, GS = 260;
 constexpr int ACTS = GT * 2 * 5 * 2 * 512;   // floats of kept activations per workgroup: [t][layer][i f g o c][q][thread]
 }  // namespace gm8
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store and load
+// (vmcnt(0)); inside the time loops the only global traffic is each thread's private kept-activation stream (written in the
+// forward sweep, read back by the same thread in the backward sweep), which needs no cross-thread ordering -- waiting for those
+// stores to be acknowledged at two barriers per step was ~15 % of the step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float xch8(float v) {      // the value lane ^ 8 holds (the other half of this 16-lane row)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
 }
@@ -802,6 +808,25 @@ __device__ __forceinline__ v4f tprod(const float* src, const float (&tb)[16][4])
     return p0;
 }
 
+#ifdef CLD_STAMPS
+// diagnostic build only: shader-clock stamps of the phases of workgroup 0..255 (read back with cld_debug_guide_stamps)
+__device__ unsigned long long g_guide_stamps[256 * 8];
+#define GSTAMP(k)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (tid == 0 && blockIdx.x < 256) {                                                        \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            g_guide_stamps[blockIdx.x * 8 + (k)] = t_;                                             \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+void read_guide_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guide_stamps), sizeof(unsigned long long) * 256 * 8); }
+#else
+#define GSTAMP(k) do {} while (0)
+void read_guide_stamps(unsigned long long*) {}
+#endif
+
 __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
     using namespace gm8;
     __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
@@ -824,6 +849,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
     const int ngroups = (a.B + AG - 1) / AG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int b0 = grp * AG;
+        GSTAMP(0);
         // kept activations go through a buffer descriptor: the per-lane part of every address is ONE VGPR (4 tid) and the
         // (step, layer, gate, row) part rides in the scalar offset -- no 64-bit vector address arithmetic per access
         const __amdgpu_buffer_rsrc_t keep = __builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * ACTS, 0, ACTS * 4, 0x00020000);
@@ -834,16 +860,33 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
         for (int i = tid; i < AG * 256; i += 512) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
         for (int i = tid; i < AG * 208; i += 512) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
         __syncthreads();
-        for (int i = tid; i < AG * 64; i += 512) {      // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49)
-            const int ag = i >> 6, uu = i & 63;
-            float s = w.b_c2h[uu];
-            const float* wr = w.w_c2h + uu * 256;
-            for (int k = 0; k < 256; ++k) s = fmaf(condm[ag][k], wr[k], s);
-            hs[0][0][ag][uu] = s;
-            hs[1][0][ag][uu] = s;
+        if (wv < 4) {      // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49): [16 agents x 256] x [256 x 64] as MFMA tiles,
+                           // wave wv = units 16 wv .. 16 wv + 15; B fragments straight from the row-major weight (16 float4 per lane, one latency)
+            const float* wr = w.w_c2h + (size_t)(16 * wv + n) * 256 + 4 * rb;
+            asm volatile("" : "+v"(wr));
+            v4f bf[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bf[j] = *reinterpret_cast<const v4f*>(wr + 16 * j);
+            const float bias = w.b_c2h[16 * wv + n];
+            v4f h0a = {bias, bias, bias, bias}, h0b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v4f ca = *reinterpret_cast<const v4f*>(&condm[n][16 * j + 4 * rb]);
+                h0a = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[0], bf[j][0], h0a, 0, 0, 0);
+                h0b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[1], bf[j][1], h0b, 0, 0, 0);
+                h0a = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[2], bf[j][2], h0a, 0, 0, 0);
+                h0b = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[3], bf[j][3], h0b, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = h0a[r] + h0b[r];
+                hs[0][0][4 * rb + r][16 * wv + n] = v;
+                hs[1][0][4 * rb + r][16 * wv + n] = v;
+            }
         }
         float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
         __syncthreads();
+        GSTAMP(1);
         // The two accumulator tiles of a layer step -> the four gate pre-activations of this lane's two (agent, unit) cells.
         // Lanes n < 8 hold P = i, Q = g, lanes n >= 8 hold P = f, Q = o (rows = agents 4rb..4rb+3); the lower half keeps
         // rows 0, 1 and the upper half rows 2, 3.
@@ -880,6 +923,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                     for (int e = 0; e < 4; ++e) { f_hh0[T][jj][e] = x0[e]; f_ih1[T][jj][e] = x1[e]; f_hh1[T][jj][e] = x2[e]; }
                 }
             }
+            GSTAMP(2);
             for (int t = 0; t < GT; ++t) {
                 const int pr = t & 1;
                 if (t > 0 && tid < 2 * AG) {      // actions of step t-1: the eight per-wave partials (written before the last barrier)
@@ -917,7 +961,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                     kput(ks + 0 + q, i_); kput(ks + 2 + q, f_); kput(ks + 4 + q, g_); kput(ks + 6 + q, o_);
                     kput(ks + 8 + q, c);
                 }
-                __syncthreads();
+                lds_barrier();
                 // ---- layer 1: pre = b + h0_t W_ih1^T + h1_{t-1} W_hh1^T ----
                 P = v4f{fb1[0], fb1[0], fb1[0], fb1[0]};
                 Q = v4f{fb1[1], fb1[1], fb1[1], fb1[1]};
@@ -956,9 +1000,10 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
 #pragma unroll
                     for (int q = 0; q < 2; ++q) { actp[pr][0][wv][ra + q] = ap[q]; actp[pr][1][wv][ra + q] = aq[q]; }
                 }
-                __syncthreads();
+                lds_barrier();
             }
         }
+        GSTAMP(3);
         // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
         if (tid < 2 * AG) {
             const int o = tid >> 4, ag = tid & 15;
@@ -971,28 +1016,23 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
         if (tid < AG)
             chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
         __syncthreads();
+        GSTAMP(4);
         // ---------------- backward through time ----------------
         {
             // B fragments of the transposed products, k-step (j, e) -> gate column col = 16 j + 4 rb + e:
             //   layer 1 tile: column n < 8 -> W_hh1[col][unit 8 wv + n], n >= 8 -> W_ih1[col][unit 8 wv + n - 8]
             //   layer 0 tile: column n < 8 -> W_hh0[col][unit 8 wv + n], 8 <= n < 12 -> W_ih0[col][latent channel n - 8], else 0
-            // One base pointer per tile, picked per lane ONCE (a per-element pointer select makes the compiler branch around
-            // every load and wait for each), opaque inside the group loop as in the forward phase; every lane loads, lanes
-            // 12..15 of the layer-0 tile drop what they read.
-            const float* p1 = (hi ? w.w_ih1 : w.w_hh1) + 4 * rb * 64 + 8 * wv + m;
-            const float* p0 = hi ? w.w_ih0 + 4 * rb * 4 + (m & 3) : w.w_hh0 + 4 * rb * 64 + 8 * wv + m;
-            asm volatile("" : "+v"(p1), "+v"(p0));
-            const int st0 = hi ? 4 : 64;                 // floats per gate column in the layer-0 source
-            const bool dead = hi && m >= 4;
+            // pre-packed at cld_finalize in exactly this order (DecoderWeights::gfrag): 32 coalesced float4 loads per lane.  The
+            // pointer is opaque inside the group loop, as in the forward phase.
+            const v4f* gf = reinterpret_cast<const v4f*>(w.gfrag) + (size_t)wv * (2 * 16 * 64) + lane;
+            asm volatile("" : "+v"(gf));
             float t1[16][4], t0[16][4];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj)
+            for (int jj = 0; jj < 16; ++jj) {
+                const v4f x1 = gf[jj * 64], x0 = gf[(16 + jj) * 64];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    t1[jj][e] = p1[(16 * jj + e) * 64];
-                    const float v = p0[(16 * jj + e) * st0];
-                    t0[jj][e] = dead ? 0.f : v;
-                }
+                for (int e = 0; e < 4; ++e) { t1[jj][e] = x1[e]; t0[jj][e] = x0[e]; }
+            }
             float rec1[2] = {0.f, 0.f}, rec0[2] = {0.f, 0.f};
             float dc1n[2] = {0.f, 0.f}, dc0n[2] = {0.f, 0.f};
             // kept activations of one (step, layer): i f g o c of this lane's two cells + the previous cell state; fetched from
@@ -1008,6 +1048,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                 for (int q = 0; q < 2; ++q) kv[5][q] = t > 0 ? kget(ks - 20 + 8 + q) : 0.f;      // the cell state of step t-1, same layer
             };
             fetch(kv1, GT - 1, 1);
+            GSTAMP(5);
             for (int t = GT - 1; t >= 0; --t) {
                 // ---- layer 1 gate gradients -> LDS ----
 #pragma unroll
@@ -1023,7 +1064,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                     row[192] = dh * tc * o_ * (1.f - o_);
                     dc1n[q] = dc * f_;
                 }
-                __syncthreads();
+                lds_barrier();
                 fetch(kv0, t, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 v4f pa = tprod(&dG[0][n][4 * rb], t1);
@@ -1049,7 +1090,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                     row[192] = dh * tc * o_ * (1.f - o_);
                     dc0n[q] = dc * f_;
                 }
-                __syncthreads();
+                lds_barrier();
                 if (t > 0) fetch(kv1, t - 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 v4f pc = tprod(&dG[1][n][4 * rb], t0);
@@ -1066,6 +1107,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             }
         }
         __syncthreads();
+        GSTAMP(6);
         // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
         for (int i = tid; i < AG * 208; i += 512) {
             const int ag = i / 208, r = i % 208, b = b0 + ag;

@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecoderWeights w, con
 // resident B fragments use the same k permutation) -- two barriers per time step, 196 MFMAs per wave per step.
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each): ~1e-7 absolute on the gates, far inside the decode bars; the libm forms cost as
 // many cycles per step here as the 196 MFMAs do
-__device__ __forceinline__ float fsig_m(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float ftanh_m(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+__device__ __forceinline__ float fsig_m(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float ftanh_m(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 __global__ __launch_bounds__(256) void decode_mfma_kernel(const DecoderWeights w, const DynParams d,
                                                           const float* __restrict__ z, const float* __restrict__ cond,

@@ -334,6 +334,10 @@ int cld_profile_read(cld_handle h, double* total_ms /*HOST*/, int64_t* launches 
  * (0..36) of every following U-Net evaluation writes 16 u64 cycle stamps per workgroup into `buf`. */
 int cld_debug_stamps(cld_handle h, void* buf /*DEVICE, u64[16 * workgroups]*/, int32_t layer);
 
+/* Diagnostic builds only (-DCLD_STAMPS; leaves `out` untouched in the shipped library): shader-clock stamps of the phases of
+ * the last guidance-kernel launch, 8 u64 per workgroup for workgroups 0..255 (scripts/guide_stamps.py). */
+int cld_debug_guide_stamps(void* out /*HOST, u64[2048]*/);
+
 /* Experiments only: every conv launch of this handle asks for at least `bytes` of dynamic LDS (0 = off), which steers how many
  * workgroups of which stream can share a CU when two handles run on two streams (scripts/exp_streams.py). */
 int cld_debug_lds_floor(cld_handle h, size_t bytes);

@@ -5,7 +5,7 @@ algorithmic FLOP (2 * rows * K * N of the layers it computes, SURVEY 8(a) layer 
 import csv, statistics, sys
 
 # MAC per agent of every launch of run_unet (csrc/cld_api.hip), in launch order; pairs are one launch
-L = [("b0.c0+res 4->64@52", 66560 + 13312), ("b0.c1 64->64@52", 1064960), ("b1.c0", 1064960), ("b1.c1", 1064960),
+L = [("b0.c0 4->64@52 (K folded)", 66560), ("b0.c1 64->64@52 (+res 1x1)", 1064960 + 13312), ("b1.c0", 1064960), ("b1.c1", 1064960),
      ("down0 k3s2", 319488), ("b2.c0+res 64->128@26", 1064960 + 212992), ("b2.c1 128->128@26", 2129920), ("b3.c0", 2129920),
      ("b3.c1", 2129920), ("down1 k3s2", 638976), ("b4.c0+res 128->256@13", 2129920 + 425984), ("b4.c1 256->256@13", 4259840),
      ("b5.c0", 4259840), ("b5.c1", 4259840), ("b6.c0", 4259840), ("b6.c1", 4259840), ("b7.c0", 4259840), ("b7.c1", 4259840),
