@@ -13,9 +13,13 @@ libs = sys.argv[2:]
 mode = os.environ.get("AB_MODE", "unet")
 prec = os.environ.get("AB_PRECISION", "f32")
 engines = []
+import ctypes
+ALL = dict(_lib.SIGNATURES)
 for path in libs:
     _lib._lib = None
     _lib.LIB_PATH = os.path.abspath(path)
+    probe = ctypes.CDLL(_lib.LIB_PATH)          # older builds may lack the newest debug entries: bind what the build exports
+    _lib.SIGNATURES = {k: v for k, v in ALL.items() if hasattr(probe, k)}
     e = Engine(100, "cuda:0", precision=prec)
     e.load_state_dict(synth.make_unet_weights(0)); e.load_state_dict(synth.make_decoder_weights(0)); e.finalize()
     engines.append(e)
