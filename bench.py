@@ -444,11 +444,12 @@ def cpu_baseline(B, wl):
             mean, _ = O.guidance_step(wd, mean, cn, cs[:k], tgt[:k], ls[:k], 0.3, None, "adam")
         return mean + sigma * z[:xs.shape[0]]
 
-    step(x, n - 1, nb=64)                                    # warm-up
+    step(x, n - 1, nb=64)                                    # warm-up (kernels, thread pool)
+    step(x, n - 1, nb=min(B, 512))                           # ... and the allocator at a realistic size
     t0 = time.perf_counter()
-    x = step(x, n - 1)                                       # probe: sizes the bounded sample (~15 s of CPU work)
+    x = step(x, n - 1)                                       # probe: sizes the bounded sample (~20 s of CPU work)
     probe = time.perf_counter() - t0
-    CPU_STEPS = max(1, min(n - 1, int(15.0 / max(probe, 1e-3))))
+    CPU_STEPS = max(1, min(n - 1, int(20.0 / max(probe, 1e-3))))
     t0 = time.perf_counter()
     for k in range(CPU_STEPS):
         x = step(x, n - 2 - k)
