@@ -46,6 +46,7 @@ struct ConvArgs {
     int ly;               // rows per agent of the OUTPUT tensor
     int off0;             // input row of tap 0 relative to STRIDE*j
     int orow0;            // output row = OSTR*j + orow0
+    int xcd_map;          // set by the launcher: XCD-aware workgroup -> tile mapping (conv_block.hip tile_of_block)
     float wscale_inv;     // split-precision mode: 1 / (power-of-two scale applied to the weights before splitting)
     unsigned long long* stamps;   // diagnostic builds (-DCLD_STAMPS) only: 16 u64 per workgroup; null otherwise
 };

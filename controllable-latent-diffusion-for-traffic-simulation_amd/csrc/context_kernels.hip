@@ -48,14 +48,23 @@ constexpr int BUF = PRW * RS;             // floats per strip image
 // barriers hide behind the MFMAs of the others: 1.44 -> 1.25 ms structured, 6.59 -> 6.42 ms dense per 256 agents
 __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const float* __restrict__ image, const float* __restrict__ wq,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       float* __restrict__ y) {
+                                                       float* __restrict__ y, int B) {
     using namespace stem;
     __shared__ float lds[2 * BUF];
-    __shared__ int plane_nz[CIN];                   // does this workgroup's strip of plane c hold any non-zero value?
+    __shared__ int plane_nz[CIN];                   // 7-bit mask per input plane: which 16-column output blocks of this strip see a non-zero value
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * TR;                 // first output row
-    const int b = blockIdx.y;
+    // Workgroup -> (agent, strip).  Neighbouring strips of an agent share 5 of their 9 input rows; dispatched as a (strip,
+    // agent) grid they land on different XCDs (blocks are dealt round-robin) and every strip is fetched from beyond L2
+    // (2.3x the raster, round-1 PMC).  Here the 56 strips of an agent get block ids L, L + 8, L + 16, ...: one XCD, back to
+    // back, so the shared rows hit that XCD's L2.  (A speed assumption only; any placement computes the same result.)
+    int b, strip;
+    {
+        const int L = blockIdx.x, NS = HO / TR, full = (B >> 3) << 3;
+        if (L < full * NS) { b = (L / (8 * NS)) * 8 + (L & 7); strip = (L >> 3) % NS; }
+        else { const int r = B - full, l2 = L - full * NS; b = full + l2 % r; strip = l2 / r; }
+    }
+    const int r0 = strip * TR;                      // first output row
     const int i16 = lane & 15, kk = lane >> 4;
 
     // ---- staging map: piece -> (byte offset inside plane 0 of this agent's raster | out of range, LDS word) ----
@@ -85,45 +94,44 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const float* __restri
         const int bufi = i / (PRW * 6), r = (i / 6) % PRW, c = i % 6;
         lds[bufi * BUF + r * RS + (c < 3 ? c : 224 + c)] = 0.f;
     }
-    // Planes are fetched PD at a time into registers: on the structured raster 31 of 34 planes contribute no MFMAs, so a
-    // plane step is one exposed load latency (~1.3 us) + LDS store + barrier, and the compiler drains every outstanding
-    // load at each use (s_waitcnt vmcnt(0)), which turns a rolling prefetch back into a distance-1 one.  A batch exposes
-    // the latency once per PD planes (PD = 2 keeps the kernel at 3 workgroups per CU; 4 and 6 are within 1 % at 2 per CU).
-#ifndef CLD_STEM_PD
-#define CLD_STEM_PD 2
-#endif
-    constexpr int PD = CLD_STEM_PD;
-    static_assert(PD % 2 == 0, "the LDS image of plane c is c & 1");
-    v4f st[PD][NPIECE];
-    auto load_group = [&](int c0) {
+    if (tid < CIN) plane_nz[tid] = 0;
+    __syncthreads();
+
+    // ---- pass 1: which planes does this strip need at all?  The history planes of the raster are almost empty (one +1 pixel
+    // for the agent and a -1 per neighbour, trajdata_utils.py:123-156): the strip of such a plane is all zeros for most
+    // workgroups and contributes exactly nothing.  One streaming read of the 34 strips (eight planes = sixteen 16-byte loads
+    // per thread in flight, no LDS, no barrier) decides it from the registers; an empty strip costs that read and nothing
+    // else -- until round 2 every plane went registers -> LDS -> barrier -> flag test, 0.62 ms of the 1.25 ms per 256 agents.
+    // plane_nz[c] = 7-bit mask of the 16-column output blocks that see a non-zero value of plane c.  Exact for any input
+    // (a zero window contributes +-0 to every sum); dense rasters simply keep every plane.
+    {
+        constexpr int G = 8;
+        for (int c0 = 0; c0 < CIN; c0 += G) {
+            v4f v[G][NPIECE];
 #pragma unroll
-        for (int k = 0; k < PD; ++k)
-            if (c0 + k < CIN) {
+            for (int k = 0; k < G; ++k)
 #pragma unroll
-                for (int i = 0; i < NPIECE; ++i) st[k][i] = cbuf_load16(rsx, voff[i], (c0 + k) * (HIN * HIN * 4));
-            }
-    };
-    // The history planes of the raster are almost empty (one +1 pixel for the agent and a -1 per neighbour,
-    // trajdata_utils.py:123-156): a 16-column output block whose input window of this plane is all zeros receives exactly
-    // nothing from it, so its 26 MFMAs per wave are skipped; plane_nz[c] is the 7-bit mask of blocks that do see a
-    // non-zero value.  Exact for any input (a zero window contributes +-0 to every sum); dense rasters keep the full loop.
-    auto store_plane = [&](int bufi, int c, int slot) {
-        int mk = 0;
+                for (int i = 0; i < NPIECE; ++i)
+                    v[k][i] = cbuf_load16(rsx, voff[i], (c0 + k < CIN ? c0 + k : CIN - 1) * (HIN * HIN * 4));
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) {
-            const v4f v = st[slot][i];
-            const bool nz = (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
-            mk |= nz ? pmask[i] : 0;
-            if (soff[i] >= 0) {
-                float* d = lds + bufi * BUF + soff[i];
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            for (int k = 0; k < G; ++k) {
+                if (c0 + k >= CIN) break;
+                int mk = 0;
+#pragma unroll
+                for (int i = 0; i < NPIECE; ++i) {
+                    const v4f x = v[k][i];
+                    mk |= ((x[0] != 0.f) | (x[1] != 0.f) | (x[2] != 0.f) | (x[3] != 0.f)) ? pmask[i] : 0;
+                }
+                if (__builtin_amdgcn_ballot_w64(mk != 0) != 0) {        // wave-uniform: most strips stop here
+                    int wm = 0;
+#pragma unroll
+                    for (int cb = 0; cb < 7; ++cb) wm |= (__builtin_amdgcn_ballot_w64((mk >> cb) & 1) != 0) ? (1 << cb) : 0;
+                    if (lane == 0) atomicOr(&plane_nz[c0 + k], wm);
+                }
             }
         }
-        int wm = 0;
-#pragma unroll
-        for (int cb = 0; cb < 7; ++cb) wm |= (__builtin_amdgcn_ballot_w64((mk >> cb) & 1) != 0) ? (1 << cb) : 0;
-        if (wm && lane == 0) atomicOr(&plane_nz[c], wm);
-    };
+    }
+    __syncthreads();
 
     // per-lane LDS byte offsets of the 13 k-steps: tap k = 4q + kk -> (kh, kw); pixel column 2 * i16
     int qoff[NQ];
@@ -139,71 +147,77 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const float* __restri
 #pragma unroll
     for (int m = 0; m < SMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
 
-    if (tid < CIN) plane_nz[tid] = 0;
-    load_group(0);
-    __syncthreads();
-    store_plane(0, 0, 0);
-    __syncthreads();
-
+    // ---- pass 2: only the planes with something in them (their strips are L2-warm from pass 1): registers -> LDS image
+    // (two images in turn: ONE barrier per plane), the next such plane's loads in flight under this plane's MFMAs ----
+    auto next_plane = [&](int c) {                   // wave-uniform scan of the 34 flags
+        while (c < CIN && __builtin_amdgcn_readfirstlane(plane_nz[c]) == 0) ++c;
+        return c;
+    };
+    v4f st[NPIECE];
+    auto load_plane = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) st[i] = cbuf_load16(rsx, voff[i], c * (HIN * HIN * 4));
+    };
     const char* ldsb = reinterpret_cast<const char*>(lds);
-    for (int c0 = 0; c0 < CIN; c0 += PD) {
+    int c = next_plane(0), cu = 0;
+    if (c < CIN) load_plane(c);
+    while (c < CIN) {
 #pragma unroll
-        for (int cr = 0; cr < PD; ++cr) {
-            const int c = c0 + cr;
-            if (c >= CIN) break;
-            const int cu = cr & 1;
-            const bool more = c + 1 < CIN;
-            const int blocks = __builtin_amdgcn_readfirstlane(plane_nz[c]);
-            if (blocks) {
-                v4f bq[4];
+        for (int i = 0; i < NPIECE; ++i)
+            if (soff[i] >= 0) {
+                float* d = lds + cu * BUF + soff[i];
+                d[0] = st[i][0]; d[1] = st[i][1]; d[2] = st[i][2]; d[3] = st[i][3];
+            }
+        const int blocks = __builtin_amdgcn_readfirstlane(plane_nz[c]);
+        const int cn = next_plane(c + 1);
+        if (cn < CIN) load_plane(cn);
+        __syncthreads();
+        v4f bq[4];
 #pragma unroll
-                for (int qg = 0; qg < 4; ++qg) bq[qg] = wq4[(c * 4 + qg) * 256];
-                if (blocks == 0x7f) {
-                    // the 14 A values of k-step q+1 are read while k-step q's MFMAs issue (one ds_read_b32 behind each MFMA, pinned)
-                    float av[2][SMT];
+        for (int qg = 0; qg < 4; ++qg) bq[qg] = wq4[(c * 4 + qg) * 256];
+        const int ib = cu * BUF * 4;
+        if (blocks == 0x7f) {
+            // the 14 A values of k-step q+1 are read while k-step q's MFMAs issue (one ds_read_b32 behind each MFMA, pinned)
+            float av[2][SMT];
 #pragma unroll
-                    for (int m = 0; m < SMT; ++m)
-                        av[0][m] = *reinterpret_cast<const float*>(ldsb + qoff[0] + cu * BUF * 4 + (2 * (m / 7) * RS + 32 * (m % 7)) * 4);
+            for (int m = 0; m < SMT; ++m)
+                av[0][m] = *reinterpret_cast<const float*>(ldsb + qoff[0] + ib + (2 * (m / 7) * RS + 32 * (m % 7)) * 4);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const int cur = q & 1;
-                        const float bv = bq[q >> 2][q & 3];
+            for (int q = 0; q < NQ; ++q) {
+                const int cur = q & 1;
+                const float bv = bq[q >> 2][q & 3];
 #pragma unroll
-                        for (int m = 0; m < SMT; ++m) {
-                            const int imm = cu * BUF * 4 + (2 * (m / 7) * RS + 32 * (m % 7)) * 4;
-                            if (q + 1 < NQ) av[cur ^ 1][m] = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm);
-                            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][m], bv, acc[m], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                } else {
-                    // sparse plane: only the column blocks that see a non-zero value (both rows of the block: M-tiles cb, cb + 7)
-#pragma unroll
-                    for (int cb = 0; cb < 7; ++cb) {
-                        if (!((blocks >> cb) & 1)) continue;
-                        const int imm0 = cu * BUF * 4 + (32 * cb) * 4, imm1 = imm0 + 2 * RS * 4;
-                        float a0 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm0);
-                        float a1 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm1);
-#pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const float bv = bq[q >> 2][q & 3];
-                            const float c0v = a0, c1v = a1;
-                            if (q + 1 < NQ) {
-                                a0 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm0);
-                                a1 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm1);
-                            }
-                            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0v, bv, acc[cb], 0, 0, 0);
-                            acc[cb + 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1v, bv, acc[cb + 7], 0, 0, 0);
-                        }
-                    }
+                for (int m = 0; m < SMT; ++m) {
+                    const int imm = (2 * (m / 7) * RS + 32 * (m % 7)) * 4;
+                    if (q + 1 < NQ) av[cur ^ 1][m] = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + ib + imm);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][m], bv, acc[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (more) {
-                if (cr == PD - 1) load_group(c + 1);    // every slot has been stored: fetch the next PD planes in one batch
-                store_plane(cu ^ 1, c + 1, (cr + 1) % PD);
+        } else {
+            // sparse plane: only the column blocks that see a non-zero value (both rows of the block: M-tiles cb, cb + 7)
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) {
+                if (!((blocks >> cb) & 1)) continue;
+                const int imm0 = ib + (32 * cb) * 4, imm1 = imm0 + 2 * RS * 4;
+                float a0 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm0);
+                float a1 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm1);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const float bv = bq[q >> 2][q & 3];
+                    const float c0v = a0, c1v = a1;
+                    if (q + 1 < NQ) {
+                        a0 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm0);
+                        a1 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm1);
+                    }
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0v, bv, acc[cb], 0, 0, 0);
+                    acc[cb + 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1v, bv, acc[cb + 7], 0, 0, 0);
+                }
             }
-            __syncthreads();
         }
+        // the image read here (cu) is rewritten two planes on, behind the next plane's barrier: no second barrier needed
+        cu ^= 1;
+        c = cn;
     }
 
     // epilogue: folded BatchNorm + ReLU; lane holds rows 4 (lane >> 4) + r of column n = 16 wave + i16 of every M-tile
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const float* __restri
 
 hipError_t launch_stem_conv(const float* image, const float* wq, const float* scale, const float* shift, float* y, int B,
                             hipStream_t s) {
-    hipLaunchKernelGGL(stem_conv_kernel, dim3(stem::HO / stem::TR, B), dim3(256), 0, s, image, wq, scale, shift, y);
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((stem::HO / stem::TR) * B), dim3(256), 0, s, image, wq, scale, shift, y, B);
     return hipGetLastError();
 }
 

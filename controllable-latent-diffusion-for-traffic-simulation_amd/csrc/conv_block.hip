@@ -632,12 +632,38 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     STAMP_RT(9);
 }
 
+// Workgroup -> tile.  The NB = c_out / NT workgroups that own the N tiles of one row block stage the SAME activation rows.
+// Launched as a (row blocks, N tiles) grid they are a whole row of the grid apart in dispatch order and never meet in a cache:
+// at 4,096 rows the dominant kernel fetched 207 MB per launch for 54.5 MB of input (round-2 PMC, profiles/r02/traffic.json
+// before this change).  With a 1-D grid and this mapping they get block ids L, L + 8, L + 16, ...: consecutive in dispatch
+// order AND -- blocks are dealt round-robin over the 8 XCDs -- on the same XCD, so three of the four reads of a row block
+// hit that XCD's L2.  Placement is a speed assumption only; any placement computes the same result.
+// Measured (interleaved A/B of whole U-Net evaluations, one process): -0.7 % at 4,096 rows per launch, where a launch is two
+// or more generations of workgroups; +0.3 % at 1,024 / 2,048 rows, where every workgroup of the launch is resident at once and
+// the four readers of a row block are better off spread over four L2s -- so the launcher asks for it (ConvArgs::xcd_map) only
+// when the grid exceeds the resident workgroup slots.
+__device__ __forceinline__ void tile_of_block(int L, int nbx, int nb, int xcd_map, int& bx, int& by) {
+    if (!xcd_map) { bx = L % nbx; by = L / nbx; return; }      // row blocks fastest, N tiles slowest
+    const int full = (nbx >> 3) << 3;                  // row blocks covered by whole groups of 8
+    if (L < full * nb) {
+        by = (L >> 3) % nb;
+        bx = (L / (8 * nb)) * 8 + (L & 7);
+    } else {
+        const int r = nbx - full, l2 = L - full * nb;
+        bx = full + l2 % r;
+        by = l2 / r;
+    }
+}
+
 // register budget: 256 (two waves per SIMD) for the exact-fp32 loop, which needs the partner wave to hide its non-MFMA
 // issue; 512 for the split-precision loop, which keeps two full fragment sets (hi + lo) in flight and is not MFMA-bound
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 __global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_block_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>(p, lds, blockIdx.x, blockIdx.y);
+    const int nb = p.c_out / (16 * NWN);
+    int bx, by;
+    tile_of_block(blockIdx.x, gridDim.x / nb, nb, p.xcd_map, bx, by);
+    conv_body<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>(p, lds, bx, by);
 }
 
 // Two launches that do not depend on each other and share a grid shape, merged into one: blockIdx.z picks the
@@ -651,8 +677,11 @@ template <int L_IN, int LM, int KC, int NWN, int KS, int GS, int OSTR, int PADC,
 __global__ __launch_bounds__(64 * NWN * KS, AIN == 1 ? 1 : 2) void conv_pair_kernel(const ConvPairArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (interleaving the two roles along x, alone or in XCD-balanced groups of 8, measured 9 % slower end to end)
-    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC, AIN, AOUT, HM>(p.a, lds, blockIdx.x, blockIdx.y);
-    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC, AIN, AOUT, HM>(p.b, lds, blockIdx.x, blockIdx.y);
+    const int nb = p.a.c_out / (16 * NWN);
+    int bx, by;
+    tile_of_block(blockIdx.x, gridDim.x / nb, nb, p.a.xcd_map, bx, by);
+    if (blockIdx.z == 0) conv_body<L_IN, LM, 1, NTAPS_A, KC, NWN, KS, EPI_A, GS, OSTR, PADC, AIN, AOUT, HM>(p.a, lds, bx, by);
+    else                 conv_body<L_IN, LM, 1, NTAPS_B, KC, NWN, KS, EPI_B, GS, OSTR, PADC, AIN, AOUT, HM>(p.b, lds, bx, by);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,8 +708,10 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 1);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_request(lds_bytes), s, a);
+    dim3 grid((b_pad / AG) * (a.c_out / (16 * NWN)), 1, 1);
+    ConvArgs aa = a;
+    aa.xcd_map = (int)grid.x > 256 * (NWN * KS == 8 ? 1 : 2);        // more workgroups than resident slots (tile_of_block)
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_request(lds_bytes), s, aa);
     return hipGetLastError();
 }
 
@@ -700,7 +731,8 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
         attr_done = true;
     }
     ConvPairArgs pa{a, b};
-    dim3 grid(b_pad / AG, a.c_out / (16 * NWN), 2);
+    dim3 grid((b_pad / AG) * (a.c_out / (16 * NWN)), 1, 2);
+    pa.a.xcd_map = pa.b.xcd_map = 2 * (int)grid.x > 256 * (NWN * KS == 8 ? 1 : 2);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWN * KS), lds_request(lds_bytes), s, pa);
     return hipGetLastError();
 }
