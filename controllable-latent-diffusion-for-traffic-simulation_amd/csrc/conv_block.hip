@@ -33,6 +33,10 @@
 //                permutation, so the sum over k is unchanged.
 #include "cld_kernels.h"
 
+#ifndef CLD_STORE_AUX
+#define CLD_STORE_AUX 16      // cache policy of the output stores: 16 = sc1 (write-through; see the epilogue), 0 = plain, 2 = nt -- A/B builds only
+#endif
+
 namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -622,9 +626,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
                 const unsigned g0 = (n & 4) ? hw[0] : lw[0], g1 = (n & 4) ? hw[1] : lw[1];
                 const unsigned r0 = __shfl_xor((int)g0, 1), r1 = __shfl_xor((int)g1, 1);
                 const u4 pw = (n & 4) ? u4{r0, r1, lw[0], lw[1]} : u4{hw[0], hw[1], r0, r1};
-                __builtin_amdgcn_raw_buffer_store_b128(pw, rsy, yoff + s22_adj + ((n & 4) ? 8 : 0) + i * ystep, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pw, rsy, yoff + s22_adj + ((n & 4) ? 8 : 0) + i * ystep, 0, CLD_STORE_AUX);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rsy, yoff + i * ystep, 0, /*aux: sc1*/ 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rsy, yoff + i * ystep, 0, /*aux: sc1*/ CLD_STORE_AUX);
             }
         }
     }
