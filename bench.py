@@ -289,7 +289,18 @@ def main():
         "roofline_whole_path_frac": round(value * FLOP_PER_STEP_AGENT * passes / 1e12 / peak_tf, 4),
     }
     if distributed:
-        out["distributed"] = {"backend": backend, "world_size_seen": dist.get_world_size(),
+        anchor = None
+        try:        # the N = 1 point of the same fixed job, as last committed by a one-GPU run (context for the curve; not measured here)
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_n1.json")), reverse=True):
+                with open(f) as fh:
+                    o = json.load(fh).get(name + "_one_gpu")
+                if o and "value" in o and not custom:
+                    anchor = {"value": o["value"], "unit": o["unit"], "source": os.path.relpath(f, ROOT) + " -> " + name + "_one_gpu"}
+                    break
+        except Exception:
+            pass
+        out["distributed"] = {"backend": backend, "world_size_seen": dist.get_world_size(), "one_gpu_anchor_committed": anchor,
                               "collective": ("all_gather_into_tensor" if r["even"] else "padded all_gather_into_tensor (uneven scene split)")
                                             + " of [B_local,52,6] once per rollout step; none inside the denoising loop"}
     if r["roof"]:
