@@ -18,6 +18,9 @@
 // holds 64 rows of column j), so no weight is re-read during the 52 steps.
 #include "cld_kernels.h"
 
+#ifndef CLD_QDEBUG
+#define CLD_QDEBUG 0      // diagnostic builds: 1 = hand back the forward actions and their gradients instead of dL/dz
+#endif
 namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1017,6 +1020,10 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
         __syncthreads();
         GSTAMP(4);
+#if CLD_QDEBUG == 1
+        for (int i = tid; i < AG * 52; i += 512) { const int ag = i / 52, t = i % 52; dz[ag][4 * t] = act[0][t][ag]; dz[ag][4 * t + 1] = act[1][t][ag]; dz[ag][4 * t + 2] = dact[ag][0][t]; dz[ag][4 * t + 3] = dact[ag][1][t]; }
+        if (false)
+#endif
         // ---------------- backward through time ----------------
         {
             // B fragments of the transposed products, k-step (j, e) -> gate column col = 16 j + 4 rb + e:
@@ -1049,7 +1056,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             };
             fetch(kv1, GT - 1, 1);
             GSTAMP(5);
-            for (int t = GT - 1; t >= 0; --t) {
+            for (int t = GT - 1; t >= (CLD_QDEBUG >= 2 ? GT - 1 : 0); --t) {
                 // ---- layer 1 gate gradients -> LDS ----
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -1076,6 +1083,9 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                     rec1[q] = hi ? got : pa[q];
                     down[q] = hi ? pa[2 + q] : got;
                 }
+#if CLD_QDEBUG == 3
+                for (int q = 0; q < 2; ++q) { dz[ra + q][u] = down[q]; dz[ra + q][64 + u] = rec1[q]; }
+#endif
                 // ---- layer 0 gate gradients -> LDS ----
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -1107,6 +1117,10 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             }
         }
         __syncthreads();
+#if CLD_QDEBUG == 2
+        for (int i = tid; i < AG * 104; i += 512) { const int ag = i / 104, c = i % 104; dz[ag][c] = dG[0][ag][c + 60]; dz[ag][104 + c] = dG[1][ag][c + 60]; }
+        __syncthreads();
+#endif
         GSTAMP(6);
         // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
         for (int i = tid; i < AG * 208; i += 512) {
@@ -1130,30 +1144,369 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
     }
 }
 
+// =============================================================================================
+// Eight agents per workgroup on the 16-block 4x4x1 fp32 MFMA: the whole chip at 2,048 agents
+// =============================================================================================
+// The 16x16x4 kernels above need 16 agents per workgroup (one M-tile), so 2,048 agents are 128 workgroups on 128 of the 256
+// CUs, and each is bound by its own MFMA issue (74 % of the time loops after round 2's clean-up): the only way to shorten a
+// guided step further is less MFMA work per CU.  v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4x4 blocks with K = 1
+// at the same fp32 rate (measured 8.4-8.8 cycles with four accumulators in turn, scripts/ubench/mfma4x4.hip: 95 % of the
+// 16x16x4 rate), so the M granularity drops to 4: 8 agents per workgroup = 256 workgroups, half the MFMA work on each CU.
+//   Transposed products: the weights are the A operand and the agents the B operand.  Forward: block = one hidden unit of this
+//   wave (16 units per wave), A row i = gate i of that unit (W[64 i + unit][k]), B column j = agent j of one quad (h[agent][k]):
+//   lane (unit, agent) receives D registers 0..3 = the i, f, g, o pre-activations of ITS cell -- all four gates of a cell in one
+//   lane with no exchange, and two MFMAs per k (the two agent quads) share the weight register.  Backward: block = (K half, which
+//   product, unit quad), A row = unit (W^T), B column = agent (the gate gradients from LDS); the two K halves are added across
+//   lane ^ 32 and a 4-way ds_bpermute hands every cell owner its unit's recurrent / downward gradient.
+//   One wave per SIMD (the K = 1 form needs one weight register per k: 196 VGPRs forward, 256 backward).
+// Kept activations, the roll-out / loss scan (chain_grad) and the optimiser step are as in the other formulations.
+namespace gq {
+constexpr int AG = 8, HS = 68, GS = 260;
+constexpr int ACTS = GT * 2 * 5 * 2 * 256;   // floats of kept activations per workgroup: [t][layer][i f g o c][agent quad][thread]
+}  // namespace gq
+
+#define CLD_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
+
+// One K sweep of the 4x4x1 products over NG groups of four k-steps: A operands wt(g) (weights, registers), B operands = the four
+// consecutive floats bptr(g, quad) points at in LDS, for the two agent quads; accumulators [quad][k parity] in turn, so no MFMA
+// waits for the one before it.  The LDS reads run two groups (16 MFMAs, ~140 cycles) ahead of their use and are pinned there
+// with scheduling barriers: with one wave per SIMD nothing else hides the read latency, and left alone the compiler issues
+// read -> wait -> 8 MFMAs -> read -> ... (measured: a guided step of 18k instead of ~10k cycles).
+template <int NG, class PF, class WF>
+__device__ __forceinline__ void qsweep(PF bptr, WF wt, v4f& a00, v4f& a01, v4f& a10, v4f& a11) {
+    v4f cur[2][2], nxt[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (j < NG) { cur[j][0] = *reinterpret_cast<const v4f*>(bptr(j, 0)); cur[j][1] = *reinterpret_cast<const v4f*>(bptr(j, 1)); }
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (g + 2 + j < NG) { nxt[j][0] = *reinterpret_cast<const v4f*>(bptr(g + 2 + j, 0)); nxt[j][1] = *reinterpret_cast<const v4f*>(bptr(g + 2 + j, 1)); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (g + j < NG) {
+                const v4f wv4 = wt(g + j);
+                a00 = CLD_MFMA4(wv4[0], cur[j][0][0], a00); a10 = CLD_MFMA4(wv4[0], cur[j][1][0], a10);
+                a01 = CLD_MFMA4(wv4[1], cur[j][0][1], a01); a11 = CLD_MFMA4(wv4[1], cur[j][1][1], a11);
+                a00 = CLD_MFMA4(wv4[2], cur[j][0][2], a00); a10 = CLD_MFMA4(wv4[2], cur[j][1][2], a10);
+                a01 = CLD_MFMA4(wv4[3], cur[j][0][3], a01); a11 = CLD_MFMA4(wv4[3], cur[j][1][3], a11);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
+    using namespace gq;
+    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
+    __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
+    __shared__ __attribute__((aligned(16))) float zin[AG][208];
+    __shared__ __attribute__((aligned(16))) float condm[AG][256];
+    __shared__ __attribute__((aligned(16))) float hpart[4][AG][HS];     // cond2hidden: the four waves' K-quarter partials
+    __shared__ float actp[2][2][4][AG];      // [step parity][output][wave][agent]: per-wave partials of hid2act
+    __shared__ float act[2][GT][AG];         // (acceleration, yaw-rate), scaled
+    __shared__ float dact[AG][2][GT];
+    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
+    __shared__ float dz[AG][208];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ul = lane >> 2, q = lane & 3;         // MFMA lane roles: block ul; A row q; B / D column q.  Cell owner: unit ul, agents q and 4 + q
+    const int u = 16 * wv + ul;                     // this lane's hidden unit
+    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
+
+    const int ngroups = (a.B + AG - 1) / AG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * AG;
+        GSTAMP(0);
+        const __amdgpu_buffer_rsrc_t keep = __builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * ACTS, 0, ACTS * 4, 0x00020000);
+        const int kvo = tid * 4;
+        auto kput = [&](int slot, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), keep, kvo, slot * 1024, 0); };
+        auto kget = [&](int slot) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(keep, kvo, slot * 1024, 0)); };
+        auto agent = [&](int ag) { return (b0 + ag < a.B) ? b0 + ag : a.B - 1; };      // tail slots replay the last agent; never stored
+        for (int i = tid; i < AG * 256; i += 256) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
+        for (int i = tid; i < AG * 208; i += 256) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
+        __syncthreads();
+        {   // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49): wave wv takes the K quarter 64 wv .. 64 wv + 63 of all 64 units
+            // (block = unit quad, A row = unit, B column = agent); the four partial tiles are added below
+            const float* wr = w.w_c2h + (size_t)(4 * ul + q) * 256 + 64 * wv;
+            asm volatile("" : "+v"(wr));
+            v4f p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v4f wa = *reinterpret_cast<const v4f*>(wr + 4 * j);
+                const v4f ca = *reinterpret_cast<const v4f*>(&condm[q][64 * wv + 4 * j]);
+                const v4f cb = *reinterpret_cast<const v4f*>(&condm[4 + q][64 * wv + 4 * j]);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    p0 = CLD_MFMA4(wa[e], ca[e], p0); p1 = CLD_MFMA4(wa[e], cb[e], p1);
+                    p2 = CLD_MFMA4(wa[e + 1], ca[e + 1], p2); p3 = CLD_MFMA4(wa[e + 1], cb[e + 1], p3);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {            // D lane (unit quad ul, agent q): register r = unit 4 ul + r
+                hpart[wv][q][4 * ul + r] = p0[r] + p2[r];
+                hpart[wv][4 + q][4 * ul + r] = p1[r] + p3[r];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < AG * 64; i += 256) {
+            const int ag = i >> 6, uu = i & 63;
+            const float v = w.b_c2h[uu] + hpart[0][ag][uu] + hpart[1][ag][uu] + hpart[2][ag][uu] + hpart[3][ag][uu];
+            hs[0][0][ag][uu] = v;
+            hs[1][0][ag][uu] = v;
+        }
+        float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
+        __syncthreads();
+        GSTAMP(1);
+        // ---------------- forward ----------------
+        {
+            // weights as A operands: lane (unit ul, gate q) holds row 64 q + u of every matrix, one register per k.  The pointers are
+            // opaque inside the group loop (see guide_mfma8_kernel)
+            const float *p_hh0 = w.w_hh0 + (size_t)(64 * q + u) * 64, *p_ih1 = w.w_ih1 + (size_t)(64 * q + u) * 64,
+                        *p_hh1 = w.w_hh1 + (size_t)(64 * q + u) * 64, *p_ih0 = w.w_ih0 + (size_t)(64 * q + u) * 4, *p_b0 = w.b0 + u, *p_b1 = w.b1 + u;
+            asm volatile("" : "+v"(p_hh0), "+v"(p_ih1), "+v"(p_hh1), "+v"(p_ih0), "+v"(p_b0), "+v"(p_b1));
+            v4f f_ih0 = *reinterpret_cast<const v4f*>(p_ih0), f_hh0[16], f_ih1[16], f_hh1[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                f_hh0[j] = *reinterpret_cast<const v4f*>(p_hh0 + 4 * j);
+                f_ih1[j] = *reinterpret_cast<const v4f*>(p_ih1 + 4 * j);
+                f_hh1[j] = *reinterpret_cast<const v4f*>(p_hh1 + 4 * j);
+            }
+            // biases: D register r = gate r of this lane's unit
+            const v4f bias0 = {p_b0[0], p_b0[64], p_b0[128], p_b0[192]}, bias1 = {p_b1[0], p_b1[64], p_b1[128], p_b1[192]};
+            const v4f zero = {0.f, 0.f, 0.f, 0.f};
+            GSTAMP(2);
+            for (int t = 0; t < GT; ++t) {
+                const int pr = t & 1;
+                if (t > 0 && tid < 2 * AG) {      // actions of step t-1: the four per-wave partials (written before the last barrier)
+                    const int o = tid >> 3, ag = tid & 7;
+                    act[o][t - 1][ag] = (o ? bh2b : bh2a) + actp[pr ^ 1][o][0][ag] + actp[pr ^ 1][o][1][ag] + actp[pr ^ 1][o][2][ag] + actp[pr ^ 1][o][3][ag];
+                }
+                // ---- layer 0: pre = b + W_ih0 x_t + W_hh0 h0_{t-1}; accumulators [agent quad][k parity] ----
+                v4f a00 = bias0, a01 = zero, a10 = bias0, a11 = zero;
+                qsweep<17>([&](int g, int aq) { return g == 0 ? &zin[4 * aq + q][4 * t] : &hs[0][pr][4 * aq + q][4 * (g > 0 ? g - 1 : 0)]; },
+                           [&](int g) { return g == 0 ? f_ih0 : f_hh0[g > 0 ? g - 1 : 0]; }, a00, a01, a10, a11);
+                int ks = (t * 2 + 0) * 10;          // slot of (step t, layer 0, gate 0, quad 0); a slot = one float per thread
+#pragma unroll
+                for (int aq = 0; aq < 2; ++aq) {
+                    const v4f P = aq ? v4f{a10[0] + a11[0], a10[1] + a11[1], a10[2] + a11[2], a10[3] + a11[3]}
+                                     : v4f{a00[0] + a01[0], a00[1] + a01[1], a00[2] + a01[2], a00[3] + a01[3]};
+                    const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
+                    const float c = f_ * c0[aq] + i_ * g_;
+                    c0[aq] = c;
+                    hs[0][pr ^ 1][4 * aq + q][u] = o_ * ftanh(c);
+                    kput(ks + 0 + aq, i_); kput(ks + 2 + aq, f_); kput(ks + 4 + aq, g_); kput(ks + 6 + aq, o_); kput(ks + 8 + aq, c);
+                }
+                lds_barrier();
+                // ---- layer 1: pre = b + W_ih1 h0_t + W_hh1 h1_{t-1} ----
+                a00 = bias1; a01 = zero; a10 = bias1; a11 = zero;
+                qsweep<32>([&](int g, int aq) { return g < 16 ? &hs[0][pr ^ 1][4 * aq + q][4 * g] : &hs[1][pr][4 * aq + q][4 * (g & 15)]; },
+                           [&](int g) { return g < 16 ? f_ih1[g & 15] : f_hh1[g & 15]; }, a00, a01, a10, a11);
+                ks += 10;
+                float ap[2], aq_[2];
+#pragma unroll
+                for (int aq = 0; aq < 2; ++aq) {
+                    const v4f P = aq ? v4f{a10[0] + a11[0], a10[1] + a11[1], a10[2] + a11[2], a10[3] + a11[3]}
+                                     : v4f{a00[0] + a01[0], a00[1] + a01[1], a00[2] + a01[2], a00[3] + a01[3]};
+                    const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
+                    const float c = f_ * c1[aq] + i_ * g_;
+                    c1[aq] = c;
+                    const float hn = o_ * ftanh(c);
+                    hs[1][pr ^ 1][4 * aq + q][u] = hn;
+                    kput(ks + 0 + aq, i_); kput(ks + 2 + aq, f_); kput(ks + 4 + aq, g_); kput(ks + 6 + aq, o_); kput(ks + 8 + aq, c);
+                    ap[aq] = hn * wa0;                      // hid2act: partials over this wave's 16 units
+                    aq_[aq] = hn * wa1;
+                }
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1)           // sum over the 16 units of the wave: lane bits 2..5
+#pragma unroll
+                    for (int aq = 0; aq < 2; ++aq) { ap[aq] += __shfl_xor(ap[aq], o); aq_[aq] += __shfl_xor(aq_[aq], o); }
+                if (ul == 0) {
+#pragma unroll
+                    for (int aq = 0; aq < 2; ++aq) { actp[pr][0][wv][4 * aq + q] = ap[aq]; actp[pr][1][wv][4 * aq + q] = aq_[aq]; }
+                }
+                lds_barrier();
+            }
+        }
+        GSTAMP(3);
+        // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
+        if (tid < 2 * AG) {
+            const int o = tid >> 3, ag = tid & 7, pl = (GT - 1) & 1;
+            act[o][GT - 1][ag] = (o ? bh2b : bh2a) + actp[pl][o][0][ag] + actp[pl][o][1][ag] + actp[pl][o][2][ag] + actp[pl][o][3][ag];
+        }
+        __syncthreads();
+        if (tid < AG)
+            chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
+        __syncthreads();
+        GSTAMP(4);
+#if CLD_QDEBUG == 1
+        for (int i = tid; i < AG * 52; i += 256) { const int ag = i / 52, t = i % 52; dz[ag][4 * t] = act[0][t][ag]; dz[ag][4 * t + 1] = act[1][t][ag]; dz[ag][4 * t + 2] = dact[ag][0][t]; dz[ag][4 * t + 3] = dact[ag][1][t]; }
+        if (false)
+#endif
+        // ---------------- backward through time ----------------
+        {
+            // A operands of the transposed products, pre-packed at cld_finalize (DecoderWeights::gqfrag): lane (block = (K half kh,
+            // product m, unit quad ub), row i) holds W_m[gate column kk + 128 kh][unit 16 wv + 4 ub + i] for kk = 0..127
+            //   layer 1: m = 0 -> W_hh1 (recurrent gradient), m = 1 -> W_ih1 (gradient flowing down to layer 0)
+            //   layer 0: m = 0 -> W_hh0, m = 1 / ub = 0 -> W_ih0[.][latent channel i] (dL/dz_t), else 0
+            const v4f* gf = reinterpret_cast<const v4f*>(w.gqfrag) + (size_t)wv * (2 * 32 * 64) + lane;
+            asm volatile("" : "+v"(gf));
+            v4f t1[32], t0[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) { t1[j] = gf[j * 64]; t0[j] = gf[(32 + j) * 64]; }
+            const int kh = lane >> 5;
+            // owner lane (unit ul, agent q) <- result lane (kh 0, product m, unit quad ul >> 2, agent q), register ul & 3
+            const int src_rec = (4 * (ul >> 2) + q) * 4, src_dwn = src_rec + 64, rsel = ul & 3;
+            // (inline asm: with __builtin_amdgcn_ds_bpermute hipcc 7.2 folds the select below into register 0 for every lane)
+            auto pick = [&](const v4f& v, int byte_lane) {
+                float x0, x1, x2, x3;
+                asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\tds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                             : "v"(byte_lane), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                return rsel == 0 ? x0 : (rsel == 1 ? x1 : (rsel == 2 ? x2 : x3));
+            };
+            // [W^T (this wave's rows) x 256 gate columns] x [256 x 8 agents]: B operand = row `gsrc` (agent q / 4 + q) of the
+            // gate-gradient tile at this lane's K half; four accumulators in turn; -> R0 / R1 (agent quads), K halves added
+            auto tprodq = [&](const float (*gsrc)[GS], const v4f (&tw)[32], v4f& R0, v4f& R1) {
+                v4f p00 = {0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+                qsweep<32>([&](int g, int aq) { return &gsrc[4 * aq + q][128 * kh + 4 * g]; }, [&](int g) { return tw[g]; }, p00, p01, p10, p11);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s0 = p00[r] + p01[r], s1 = p10[r] + p11[r];
+                    R0[r] = s0 + __shfl_xor(s0, 32);
+                    R1[r] = s1 + __shfl_xor(s1, 32);
+                }
+            };
+            float rec1[2] = {0.f, 0.f}, rec0[2] = {0.f, 0.f};
+            float dc1n[2] = {0.f, 0.f}, dc0n[2] = {0.f, 0.f};
+            float kv1[6][2], kv0[6][2];
+            auto fetch = [&](float (&kv)[6][2], int t, int layer) {
+                const int ks = (t * 2 + layer) * 10;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+#pragma unroll
+                    for (int aq = 0; aq < 2; ++aq) kv[k][aq] = kget(ks + 2 * k + aq);
+#pragma unroll
+                for (int aq = 0; aq < 2; ++aq) kv[5][aq] = t > 0 ? kget(ks - 20 + 8 + aq) : 0.f;      // the cell state of step t-1, same layer
+            };
+            fetch(kv1, GT - 1, 1);
+            GSTAMP(5);
+            for (int t = GT - 1; t >= (CLD_QDEBUG >= 2 ? GT - 1 : 0); --t) {
+                // ---- layer 1 gate gradients -> LDS ----
+#pragma unroll
+                for (int aq = 0; aq < 2; ++aq) {
+                    const float i_ = kv1[0][aq], f_ = kv1[1][aq], g_ = kv1[2][aq], o_ = kv1[3][aq], c = kv1[4][aq], cp = kv1[5][aq];
+                    const float tc = ftanh(c);
+                    const float dh = wa0 * dact[4 * aq + q][0][t] + wa1 * dact[4 * aq + q][1][t] + rec1[aq];
+                    const float dc = dh * o_ * (1.f - tc * tc) + dc1n[aq];
+                    float* row = &dG[0][4 * aq + q][u];
+                    row[0] = dc * g_ * i_ * (1.f - i_);
+                    row[64] = dc * cp * f_ * (1.f - f_);
+                    row[128] = dc * i_ * (1.f - g_ * g_);
+                    row[192] = dh * tc * o_ * (1.f - o_);
+                    dc1n[aq] = dc * f_;
+                }
+                lds_barrier();
+                fetch(kv0, t, 0);
+                v4f R0, R1;
+                tprodq(dG[0], t1, R0, R1);
+                float down[2];
+                rec1[0] = pick(R0, src_rec); rec1[1] = pick(R1, src_rec);
+                down[0] = pick(R0, src_dwn); down[1] = pick(R1, src_dwn);
+#if CLD_QDEBUG == 3
+                for (int aq = 0; aq < 2; ++aq) { dz[4 * aq + q][u] = down[aq]; dz[4 * aq + q][64 + u] = rec1[aq]; }
+#endif
+                // ---- layer 0 gate gradients -> LDS ----
+#pragma unroll
+                for (int aq = 0; aq < 2; ++aq) {
+                    const float i_ = kv0[0][aq], f_ = kv0[1][aq], g_ = kv0[2][aq], o_ = kv0[3][aq], c = kv0[4][aq], cp = kv0[5][aq];
+                    const float tc = ftanh(c);
+                    const float dh = down[aq] + rec0[aq];
+                    const float dc = dh * o_ * (1.f - tc * tc) + dc0n[aq];
+                    float* row = &dG[1][4 * aq + q][u];
+                    row[0] = dc * g_ * i_ * (1.f - i_);
+                    row[64] = dc * cp * f_ * (1.f - f_);
+                    row[128] = dc * i_ * (1.f - g_ * g_);
+                    row[192] = dh * tc * o_ * (1.f - o_);
+                    dc0n[aq] = dc * f_;
+                }
+                lds_barrier();
+                if (t > 0) fetch(kv1, t - 1, 1);
+                tprodq(dG[1], t0, R0, R1);
+                rec0[0] = pick(R0, src_rec); rec0[1] = pick(R1, src_rec);
+                // dL/dz_t, complete: result lanes (kh 0, product 1, unit quad 0, agent q) = lanes 16..19, register r = latent channel r
+                if (wv == 0 && lane >= 16 && lane < 20) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dz[q][4 * t + r] = R0[r]; dz[4 + q][4 * t + r] = R1[r]; }
+                }
+            }
+        }
+        __syncthreads();
+        GSTAMP(6);
+#if CLD_QDEBUG == 2
+        for (int i = tid; i < AG * 104; i += 256) { const int ag = i / 104, c = i % 104; dz[ag][c] = dG[0][ag][c + 60]; dz[ag][104 + c] = dG[1][ag][c + 60]; }
+        __syncthreads();
+#endif
+        // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
+        for (int i = tid; i < AG * 208; i += 256) {
+            const int ag = i / 208, r = i % 208, b = b0 + ag;
+            if (b >= a.B) continue;
+            const float g = dz[ag][r];
+            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
+            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
+            const float mu = zin[ag][r] + delta;
+            if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
+            if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
+            if (a.x_out) {
+                float zz = 0.f;
+                if (a.sigma != 0.f) zz = a.z ? a.z[(size_t)b * 208 + r] : normal4(a.seed, a.step_salt, (unsigned)(b * 52 + (r >> 2)))[r & 3];
+                const float xn = mu + a.sigma * zz;
+                a.x_out[(size_t)b * 208 + r] = xn;
+                if (a.x_out2) a.x_out2[(size_t)b * 208 + r] = xn;
+            }
+        }
+        GSTAMP(7);
+        __syncthreads();
+    }
+}
+
 static int guide_mfma_grid(int B) {
     const int groups = (B + gm::AG - 1) / gm::AG;
     return groups < 256 ? groups : 256;
 }
-// The MFMA kernel needs >= 16 agents per workgroup to pay off and one workgroup per CU to fill the chip: from 512 agents
-// (32 workgroups) up it is faster than the 2-agent VALU kernel (tests force either form through cld_debug_force_kernel).
-static bool use_mfma_guide(int B, int form) {
-    if (form == FORM_VALU) return false;
-    if (form == FORM_MFMA || form == FORM_MFMA_4WAVE) return true;
-    return B >= 512;
+static int guide_quad_grid(int B) {
+    const int groups = (B + gq::AG - 1) / gq::AG;
+    return groups < 256 ? groups : 256;
+}
+// Which formulation by batch size.  The MFMA kernels need one workgroup per CU to fill the chip and each workgroup is bound by
+// its own MFMA issue, so what counts is the number of ROUNDS of workgroups over the 256 CUs: the 8-agent kernel (a round costs
+// ~0.6 of a 16-agent round) wins while it needs no more rounds than the 16-agent kernel would, i.e. up to 2,048 agents and
+// again wherever ceil(B / 2048) == ceil(B / 4096) fails to hold the other way; below 256 agents the 2-agent VALU kernel
+// (more workgroups) is faster.  Tests force each form through cld_debug_force_kernel.
+static int guide_form(int B, int form) {
+    if (form != FORM_AUTO) return form;
+    if (B < 256) return FORM_VALU;
+    const int r8 = (B + 8 * 256 - 1) / (8 * 256), r16 = (B + 16 * 256 - 1) / (16 * 256);
+    return 3 * r8 <= 5 * r16 ? FORM_MFMA_QUAD : FORM_MFMA;
 }
 size_t guide_scratch_floats(int B) {
     const size_t valu = (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS);
-    static_assert(gm::ACTS == gm8::ACTS, "both MFMA formulations keep the same number of activations per workgroup");
-    const size_t mfma = (size_t)guide_mfma_grid(B) * gm::ACTS;
-    return valu > mfma ? valu : mfma;
+    static_assert(gm::ACTS == gm8::ACTS, "both 16-agent MFMA formulations keep the same number of activations per workgroup");
+    const size_t mfma = (size_t)guide_mfma_grid(B) * gm::ACTS, quad = (size_t)guide_quad_grid(B) * gq::ACTS;
+    return valu > mfma ? (valu > quad ? valu : quad) : (mfma > quad ? mfma : quad);
 }
 
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
-    if (use_mfma_guide(a.B, form)) {
-        if (form == FORM_MFMA_4WAVE) hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a);
-        else hipLaunchKernelGGL(guide_mfma8_kernel, dim3(guide_mfma_grid(a.B)), dim3(512), 0, s, w, d, a);
+    switch (guide_form(a.B, form)) {
+        case FORM_MFMA_QUAD: hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(256), 0, s, w, d, a); break;
+        case FORM_MFMA_4WAVE: hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a); break;
+        case FORM_MFMA: hipLaunchKernelGGL(guide_mfma8_kernel, dim3(guide_mfma_grid(a.B)), dim3(512), 0, s, w, d, a); break;
+        default: hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
     }
-    else hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
     return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ for B in [int(a) for a in sys.argv[1:]] or [2048]:
     z = torch.randn(B, 52, 4, device="cuda", generator=g)
     gd = {"curr_states": cs, "target_speed": torch.rand(B, 52, device="cuda", generator=g) * 12, "lr": 0.3, "optimizer": "adam"}
     outs = {}
-    for name, form in (("mfma 4 waves", 3), ("mfma 8 waves", 2), ("valu", 1)):
+    for name, form in (("quad 4x4x1", 4), ("mfma 4 waves", 3), ("mfma 8 waves", 2), ("valu", 1)):
         e._check(e.lib.cld_debug_force_kernel(e._h, 0, form), "force")
         for _ in range(3):
             out = e.guidance_step(mean, cond, gd, 0.5, z=z, want_grad=True)
@@ -29,4 +29,5 @@ for B in [int(a) for a in sys.argv[1:]] or [2048]:
         outs[name] = out
         print(f"B={B} {name:14s}: median {sorted(ts)[3]*1e3:8.1f} us  min {min(ts)*1e3:8.1f} us (incl. ~3 small torch allocations per call)")
     ga, gb = outs["mfma 4 waves"][2], outs["mfma 8 waves"][2]
-    print("   max |grad 8w - grad 4w| =", float((ga - gb).abs().max()), " max |grad| =", float(ga.abs().max()))
+    print("   max |grad 8w - grad 4w| =", float((ga - gb).abs().max()), " max |grad quad - grad 4w| =", float((outs["quad 4x4x1"][2] - ga).abs().max()),
+          " max |grad| =", float(ga.abs().max()))
