@@ -577,7 +577,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 2 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 4 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 2 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 5 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }

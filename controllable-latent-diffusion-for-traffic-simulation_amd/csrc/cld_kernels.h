@@ -134,7 +134,8 @@ struct DynParams {
 // Kernel formulation of the three recurrent kernels (decode / encode / guide): picked by batch size unless a test forces one
 // through cld_debug_force_kernel.
 enum { FORM_AUTO = 0, FORM_VALU = 1, FORM_MFMA = 2, FORM_MFMA_4WAVE = 3 /* guide kernel only: the one-wave-per-SIMD MFMA form, kept for A/B */,
-       FORM_MFMA_QUAD = 4 /* guide kernel only: 8 agents per workgroup on the 4x4x1 MFMA */ };
+       FORM_MFMA_QUAD = 4 /* guide kernel only: 8 agents per workgroup on the 4x4x1 MFMA */,
+       FORM_MFMA_QUAD2 = 5 /* guide kernel only: the same with K split between two waves per SIMD */ };
 // z [B,52,4], cond [B,256] -> act [B,52,2] (optional) ; if cs != null also traj [B,52,6]
 hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond,
                          const float* cs, float* act, float* traj, int B, int descaled_output, hipStream_t s, int form = FORM_AUTO);

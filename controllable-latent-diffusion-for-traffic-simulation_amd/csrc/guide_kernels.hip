@@ -18,9 +18,6 @@
 // holds 64 rows of column j), so no weight is re-read during the 52 steps.
 #include "cld_kernels.h"
 
-#ifndef CLD_QDEBUG
-#define CLD_QDEBUG 0      // diagnostic builds: 1 = hand back the forward actions and their gradients instead of dL/dz
-#endif
 namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -825,7 +822,15 @@ __device__ unsigned long long g_guide_stamps[256 * 8];
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
 void read_guide_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guide_stamps), sizeof(unsigned long long) * 256 * 8); }
+#define GPHASE_DECL unsigned long long ph_[16] = {0}, phl_ = 0
+#define GPHASE_START do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(phl_)::"memory"); } while (0)
+#define GPHASE(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ph_[k] += t_ - phl_; phl_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GPHASE_PRINT(n) do { if (tid == 0 && blockIdx.x == 0) for (int i_ = 0; i_ < (n); ++i_) printf("phase %2d: %8llu cycles (%6.0f per step)\n", i_, ph_[i_], (double)ph_[i_] / 52.0); } while (0)
 #else
+#define GPHASE_DECL do {} while (0)
+#define GPHASE_START do {} while (0)
+#define GPHASE(k) do {} while (0)
+#define GPHASE_PRINT(n) do {} while (0)
 #define GSTAMP(k) do {} while (0)
 void read_guide_stamps(unsigned long long*) {}
 #endif
@@ -1020,10 +1025,6 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
         __syncthreads();
         GSTAMP(4);
-#if CLD_QDEBUG == 1
-        for (int i = tid; i < AG * 52; i += 512) { const int ag = i / 52, t = i % 52; dz[ag][4 * t] = act[0][t][ag]; dz[ag][4 * t + 1] = act[1][t][ag]; dz[ag][4 * t + 2] = dact[ag][0][t]; dz[ag][4 * t + 3] = dact[ag][1][t]; }
-        if (false)
-#endif
         // ---------------- backward through time ----------------
         {
             // B fragments of the transposed products, k-step (j, e) -> gate column col = 16 j + 4 rb + e:
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             };
             fetch(kv1, GT - 1, 1);
             GSTAMP(5);
-            for (int t = GT - 1; t >= (CLD_QDEBUG >= 2 ? GT - 1 : 0); --t) {
+            for (int t = GT - 1; t >= 0; --t) {
                 // ---- layer 1 gate gradients -> LDS ----
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -1083,9 +1084,6 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
                     rec1[q] = hi ? got : pa[q];
                     down[q] = hi ? pa[2 + q] : got;
                 }
-#if CLD_QDEBUG == 3
-                for (int q = 0; q < 2; ++q) { dz[ra + q][u] = down[q]; dz[ra + q][64 + u] = rec1[q]; }
-#endif
                 // ---- layer 0 gate gradients -> LDS ----
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -1117,10 +1115,6 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             }
         }
         __syncthreads();
-#if CLD_QDEBUG == 2
-        for (int i = tid; i < AG * 104; i += 512) { const int ag = i / 104, c = i % 104; dz[ag][c] = dG[0][ag][c + 60]; dz[ag][104 + c] = dG[1][ag][c + 60]; }
-        __syncthreads();
-#endif
         GSTAMP(6);
         // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
         for (int i = tid; i < AG * 208; i += 512) {
@@ -1167,26 +1161,65 @@ constexpr int ACTS = GT * 2 * 5 * 2 * 256;   // floats of kept activations per w
 
 #define CLD_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
+// The value the lane byte_lane / 4 holds.  By-value float on purpose: __builtin_bit_cast(int, v[r]) of an ext-vector ELEMENT reads
+// element 0 whatever r is (hipcc 7.2), which silently turns a four-register exchange into four copies of register 0.
+__device__ __forceinline__ float bperm(int byte_lane, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_lane, __builtin_bit_cast(int, v)));
+}
+
+
+// K sweep of the 4x4x1 products with the AGENTS' values as the broadcast A operand (rows = the four agents of a quad).
+//   X0 / X1 (quad 0 / quad 1): register c holds, in the lanes of block b, four consecutive k-steps of k-group PER c + b for
+//   row (lane & 3) -- ONE ds_read_b128 per register feeds PER = 16 (CB = 4) or 8 (CB = 3: one broadcast group per K half)
+//   k-groups: the MFMA's cbsz / abid fields hand block `abid`'s rows to every block of its group.  With every lane fetching its
+//   own copy of the operand (qsweep below) the four waves pulled 98 + 128 KB per step and wave through the CU's 128 B/clk LDS
+//   port -- as long as the MFMAs themselves take (profiles/r02/guide_kernel_notes.md) -- and spent an issue slot per 8 MFMAs.
+//   B operand = the weights wt(g) (columns; one register per k, resident).  Accumulators [quad][k parity] in turn, so no MFMA
+//   waits for the one before it.  (abid is an immediate, hence the compile-time recursion over the k-groups.)
+template <int G, int NG, int CB, class WF>
+__device__ __forceinline__ void bsweep(const v4f* X0, const v4f* X1, WF wt, v4f& a00, v4f& a01, v4f& a10, v4f& a11) {
+    if constexpr (G < NG) {
+        constexpr int PER = 1 << CB, c = G / PER, ab = G % PER;
+        const v4f wv4 = wt(G);
+        a00 = __builtin_amdgcn_mfma_f32_4x4x1f32(X0[c][0], wv4[0], a00, CB, ab, 0); a10 = __builtin_amdgcn_mfma_f32_4x4x1f32(X1[c][0], wv4[0], a10, CB, ab, 0);
+        a01 = __builtin_amdgcn_mfma_f32_4x4x1f32(X0[c][1], wv4[1], a01, CB, ab, 0); a11 = __builtin_amdgcn_mfma_f32_4x4x1f32(X1[c][1], wv4[1], a11, CB, ab, 0);
+        a00 = __builtin_amdgcn_mfma_f32_4x4x1f32(X0[c][2], wv4[2], a00, CB, ab, 0); a10 = __builtin_amdgcn_mfma_f32_4x4x1f32(X1[c][2], wv4[2], a10, CB, ab, 0);
+        a01 = __builtin_amdgcn_mfma_f32_4x4x1f32(X0[c][3], wv4[3], a01, CB, ab, 0); a11 = __builtin_amdgcn_mfma_f32_4x4x1f32(X1[c][3], wv4[3], a11, CB, ab, 0);
+        bsweep<G + 1, NG, CB>(X0, X1, wt, a00, a01, a10, a11);
+    }
+}
+
+// 4 x 4 transpose across the four lanes of a quad: out[g] = register (lane & 3) of the quad's lane g.  Two butterfly stages
+// (lane bit 0 with register bit 0, then bit 1 with bit 1), each one select for what to send, one DPP quad permute, two selects.
+__device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false)); }
+__device__ __forceinline__ float quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E /* quad_perm:[2,3,0,1] */, 0xf, 0xf, false)); }
+__device__ __forceinline__ v4f quad_transpose(const v4f& x, bool odd1, bool odd2) {
+    const float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    const float r01 = quad_xor1(odd1 ? x0 : x1), r23 = quad_xor1(odd1 ? x2 : x3);
+    const float y0 = odd1 ? r01 : x0, y1 = odd1 ? x1 : r01, y2 = odd1 ? r23 : x2, y3 = odd1 ? x3 : r23;
+    const float r02 = quad_xor2(odd2 ? y0 : y2), r13 = quad_xor2(odd2 ? y1 : y3);
+    return v4f{odd2 ? r02 : y0, odd2 ? r13 : y1, odd2 ? y2 : r02, odd2 ? y3 : r13};
+}
 
 // One K sweep of the 4x4x1 products over NG groups of four k-steps: A operands wt(g) (weights, registers), B operands = the four
 // consecutive floats bptr(g, quad) points at in LDS, for the two agent quads; accumulators [quad][k parity] in turn, so no MFMA
 // waits for the one before it.  The LDS reads run two groups (16 MFMAs, ~140 cycles) ahead of their use and are pinned there
 // with scheduling barriers: with one wave per SIMD nothing else hides the read latency, and left alone the compiler issues
 // read -> wait -> 8 MFMAs -> read -> ... (measured: a guided step of 18k instead of ~10k cycles).
-template <int NG, class PF, class WF>
+template <int NG, int D = 2, class PF, class WF>
 __device__ __forceinline__ void qsweep(PF bptr, WF wt, v4f& a00, v4f& a01, v4f& a10, v4f& a11) {
-    v4f cur[2][2], nxt[2][2];
+    v4f cur[D][2], nxt[D][2];        // D groups per scheduling region, fetched D groups ahead
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < D; ++j)
         if (j < NG) { cur[j][0] = *reinterpret_cast<const v4f*>(bptr(j, 0)); cur[j][1] = *reinterpret_cast<const v4f*>(bptr(j, 1)); }
 #pragma unroll
-    for (int g = 0; g < NG; g += 2) {
+    for (int g = 0; g < NG; g += D) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (g + 2 + j < NG) { nxt[j][0] = *reinterpret_cast<const v4f*>(bptr(g + 2 + j, 0)); nxt[j][1] = *reinterpret_cast<const v4f*>(bptr(g + 2 + j, 1)); }
+        for (int j = 0; j < D; ++j)
+            if (g + D + j < NG) { nxt[j][0] = *reinterpret_cast<const v4f*>(bptr(g + D + j, 0)); nxt[j][1] = *reinterpret_cast<const v4f*>(bptr(g + D + j, 1)); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < D; ++j)
             if (g + j < NG) {
                 const v4f wv4 = wt(g + j);
                 a00 = CLD_MFMA4(wv4[0], cur[j][0][0], a00); a10 = CLD_MFMA4(wv4[0], cur[j][1][0], a10);
@@ -1196,7 +1229,7 @@ __device__ __forceinline__ void qsweep(PF bptr, WF wt, v4f& a00, v4f& a01, v4f& 
             }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+        for (int j = 0; j < D; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
     }
 }
 
@@ -1259,13 +1292,16 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
             hs[0][0][ag][uu] = v;
             hs[1][0][ag][uu] = v;
         }
+        GPHASE_DECL;
         float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
         __syncthreads();
         GSTAMP(1);
         // ---------------- forward ----------------
         {
-            // weights as A operands: lane (unit ul, gate q) holds row 64 q + u of every matrix, one register per k.  The pointers are
-            // opaque inside the group loop (see guide_mfma8_kernel)
+            // weights as B operands: lane (block = unit ul, column = gate q) holds row 64 q + u of every matrix, one register per k; a
+            // sweep leaves gate q of unit u for the four agents of a quad in this lane's four registers, and a 4 x 4 transpose across
+            // the quad's lanes (the four gates of the unit) hands lane (ul, a) all four gates of agent a.  The pointers are opaque
+            // inside the group loop (see guide_mfma8_kernel)
             const float *p_hh0 = w.w_hh0 + (size_t)(64 * q + u) * 64, *p_ih1 = w.w_ih1 + (size_t)(64 * q + u) * 64,
                         *p_hh1 = w.w_hh1 + (size_t)(64 * q + u) * 64, *p_ih0 = w.w_ih0 + (size_t)(64 * q + u) * 4, *p_b0 = w.b0 + u, *p_b1 = w.b1 + u;
             asm volatile("" : "+v"(p_hh0), "+v"(p_ih1), "+v"(p_hh1), "+v"(p_ih0), "+v"(p_b0), "+v"(p_b1));
@@ -1276,10 +1312,12 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
                 f_ih1[j] = *reinterpret_cast<const v4f*>(p_ih1 + 4 * j);
                 f_hh1[j] = *reinterpret_cast<const v4f*>(p_hh1 + 4 * j);
             }
-            // biases: D register r = gate r of this lane's unit
-            const v4f bias0 = {p_b0[0], p_b0[64], p_b0[128], p_b0[192]}, bias1 = {p_b1[0], p_b1[64], p_b1[128], p_b1[192]};
+            // biases: this lane's column is gate q of unit u; D register r = agent r of the quad
+            const float bq0 = p_b0[64 * q], bq1 = p_b1[64 * q];
+            const v4f bias0 = {bq0, bq0, bq0, bq0}, bias1 = {bq1, bq1, bq1, bq1};
             const v4f zero = {0.f, 0.f, 0.f, 0.f};
             GSTAMP(2);
+            GPHASE_START;
             for (int t = 0; t < GT; ++t) {
                 const int pr = t & 1;
                 if (t > 0 && tid < 2 * AG) {      // actions of step t-1: the four per-wave partials (written before the last barrier)
@@ -1288,30 +1326,41 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
                 }
                 // ---- layer 0: pre = b + W_ih0 x_t + W_hh0 h0_{t-1}; accumulators [agent quad][k parity] ----
                 v4f a00 = bias0, a01 = zero, a10 = bias0, a11 = zero;
-                qsweep<17>([&](int g, int aq) { return g == 0 ? &zin[4 * aq + q][4 * t] : &hs[0][pr][4 * aq + q][4 * (g > 0 ? g - 1 : 0)]; },
-                           [&](int g) { return g == 0 ? f_ih0 : f_hh0[g > 0 ? g - 1 : 0]; }, a00, a01, a10, a11);
+                {
+                    // lane (block ul, row q): agent 4 aq + q, k-group ul of h0_{t-1}; x_t: the same four channels in every block
+                    const v4f Xh[2] = {*reinterpret_cast<const v4f*>(&hs[0][pr][q][4 * ul]), *reinterpret_cast<const v4f*>(&hs[0][pr][4 + q][4 * ul])};
+                    const v4f Xx[2] = {*reinterpret_cast<const v4f*>(&zin[q][4 * t]), *reinterpret_cast<const v4f*>(&zin[4 + q][4 * t])};
+                    bsweep<0, 1, 4>(&Xx[0], &Xx[1], [&](int) { return f_ih0; }, a00, a01, a10, a11);
+                    bsweep<0, 16, 4>(&Xh[0], &Xh[1], [&](int g) { return f_hh0[g]; }, a00, a01, a10, a11);
+                }
+                GPHASE(0);
                 int ks = (t * 2 + 0) * 10;          // slot of (step t, layer 0, gate 0, quad 0); a slot = one float per thread
 #pragma unroll
                 for (int aq = 0; aq < 2; ++aq) {
-                    const v4f P = aq ? v4f{a10[0] + a11[0], a10[1] + a11[1], a10[2] + a11[2], a10[3] + a11[3]}
-                                     : v4f{a00[0] + a01[0], a00[1] + a01[1], a00[2] + a01[2], a00[3] + a01[3]};
+                    const v4f P = quad_transpose(aq ? a10 + a11 : a00 + a01, q & 1, q & 2);      // gate q x four agents -> agent q x four gates
                     const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
                     const float c = f_ * c0[aq] + i_ * g_;
                     c0[aq] = c;
                     hs[0][pr ^ 1][4 * aq + q][u] = o_ * ftanh(c);
                     kput(ks + 0 + aq, i_); kput(ks + 2 + aq, f_); kput(ks + 4 + aq, g_); kput(ks + 6 + aq, o_); kput(ks + 8 + aq, c);
                 }
+                GPHASE(1);
                 lds_barrier();
+                GPHASE(2);
                 // ---- layer 1: pre = b + W_ih1 h0_t + W_hh1 h1_{t-1} ----
                 a00 = bias1; a01 = zero; a10 = bias1; a11 = zero;
-                qsweep<32>([&](int g, int aq) { return g < 16 ? &hs[0][pr ^ 1][4 * aq + q][4 * g] : &hs[1][pr][4 * aq + q][4 * (g & 15)]; },
-                           [&](int g) { return g < 16 ? f_ih1[g & 15] : f_hh1[g & 15]; }, a00, a01, a10, a11);
+                {
+                    const v4f Xa[2] = {*reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][q][4 * ul]), *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][4 + q][4 * ul])};
+                    const v4f Xb[2] = {*reinterpret_cast<const v4f*>(&hs[1][pr][q][4 * ul]), *reinterpret_cast<const v4f*>(&hs[1][pr][4 + q][4 * ul])};
+                    bsweep<0, 16, 4>(&Xa[0], &Xa[1], [&](int g) { return f_ih1[g]; }, a00, a01, a10, a11);
+                    bsweep<0, 16, 4>(&Xb[0], &Xb[1], [&](int g) { return f_hh1[g]; }, a00, a01, a10, a11);
+                }
+                GPHASE(3);
                 ks += 10;
                 float ap[2], aq_[2];
 #pragma unroll
                 for (int aq = 0; aq < 2; ++aq) {
-                    const v4f P = aq ? v4f{a10[0] + a11[0], a10[1] + a11[1], a10[2] + a11[2], a10[3] + a11[3]}
-                                     : v4f{a00[0] + a01[0], a00[1] + a01[1], a00[2] + a01[2], a00[3] + a01[3]};
+                    const v4f P = quad_transpose(aq ? a10 + a11 : a00 + a01, q & 1, q & 2);      // gate q x four agents -> agent q x four gates
                     const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
                     const float c = f_ * c1[aq] + i_ * g_;
                     c1[aq] = c;
@@ -1329,7 +1378,9 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
 #pragma unroll
                     for (int aq = 0; aq < 2; ++aq) { actp[pr][0][wv][4 * aq + q] = ap[aq]; actp[pr][1][wv][4 * aq + q] = aq_[aq]; }
                 }
+                GPHASE(4);
                 lds_barrier();
+                GPHASE(5);
             }
         }
         GSTAMP(3);
@@ -1343,14 +1394,10 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
             chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
         __syncthreads();
         GSTAMP(4);
-#if CLD_QDEBUG == 1
-        for (int i = tid; i < AG * 52; i += 256) { const int ag = i / 52, t = i % 52; dz[ag][4 * t] = act[0][t][ag]; dz[ag][4 * t + 1] = act[1][t][ag]; dz[ag][4 * t + 2] = dact[ag][0][t]; dz[ag][4 * t + 3] = dact[ag][1][t]; }
-        if (false)
-#endif
         // ---------------- backward through time ----------------
         {
-            // A operands of the transposed products, pre-packed at cld_finalize (DecoderWeights::gqfrag): lane (block = (K half kh,
-            // product m, unit quad ub), row i) holds W_m[gate column kk + 128 kh][unit 16 wv + 4 ub + i] for kk = 0..127
+            // B operands of the products, pre-packed at cld_finalize (DecoderWeights::gqfrag): lane (block = (K half kh, product m,
+            // unit quad ub), column j) holds W_m[gate column kk + 128 kh][unit 16 wv + 4 ub + j] for kk = 0..127
             //   layer 1: m = 0 -> W_hh1 (recurrent gradient), m = 1 -> W_ih1 (gradient flowing down to layer 0)
             //   layer 0: m = 0 -> W_hh0, m = 1 / ub = 0 -> W_ih0[.][latent channel i] (dL/dz_t), else 0
             const v4f* gf = reinterpret_cast<const v4f*>(w.gqfrag) + (size_t)wv * (2 * 32 * 64) + lane;
@@ -1359,21 +1406,23 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
 #pragma unroll
             for (int j = 0; j < 32; ++j) { t1[j] = gf[j * 64]; t0[j] = gf[(32 + j) * 64]; }
             const int kh = lane >> 5;
-            // owner lane (unit ul, agent q) <- result lane (kh 0, product m, unit quad ul >> 2, agent q), register ul & 3
-            const int src_rec = (4 * (ul >> 2) + q) * 4, src_dwn = src_rec + 64, rsel = ul & 3;
-            // (inline asm: with __builtin_amdgcn_ds_bpermute hipcc 7.2 folds the select below into register 0 for every lane)
+            // owner lane (unit ul, agent q) <- result lane (kh 0, product m, unit quad ul >> 2, column ul & 3) = lane 16 m + ul, register q
+            const int src_rec = ul * 4, src_dwn = src_rec + 64, rsel = q;
             auto pick = [&](const v4f& v, int byte_lane) {
-                float x0, x1, x2, x3;
-                asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\tds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                             : "v"(byte_lane), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                const float x0 = bperm(byte_lane, v[0]), x1 = bperm(byte_lane, v[1]), x2 = bperm(byte_lane, v[2]), x3 = bperm(byte_lane, v[3]);
                 return rsel == 0 ? x0 : (rsel == 1 ? x1 : (rsel == 2 ? x2 : x3));
             };
-            // [W^T (this wave's rows) x 256 gate columns] x [256 x 8 agents]: B operand = row `gsrc` (agent q / 4 + q) of the
-            // gate-gradient tile at this lane's K half; four accumulators in turn; -> R0 / R1 (agent quads), K halves added
+            // [8 agents x 256 gate columns] x [256 x this wave's 32 columns]: A operand = the agents' rows of the gate-gradient tile,
+            // one K half per broadcast group of 8 blocks: lane (kh, block b of the half, row q) reads the four columns of k-group
+            // 8 c + b of its half -> R0 / R1 (agent quads), K halves added
             auto tprodq = [&](const float (*gsrc)[GS], const v4f (&tw)[32], v4f& R0, v4f& R1) {
                 v4f p00 = {0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
-                qsweep<32>([&](int g, int aq) { return &gsrc[4 * aq + q][128 * kh + 4 * g]; }, [&](int g) { return tw[g]; }, p00, p01, p10, p11);
+                const float* g0 = &gsrc[q][128 * kh + 4 * (ul & 7)];
+                const float* g1 = &gsrc[4 + q][128 * kh + 4 * (ul & 7)];
+                v4f X0[4], X1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { X0[c] = *reinterpret_cast<const v4f*>(g0 + 32 * c); X1[c] = *reinterpret_cast<const v4f*>(g1 + 32 * c); }
+                bsweep<0, 32, 3>(X0, X1, [&](int g) { return tw[g]; }, p00, p01, p10, p11);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float s0 = p00[r] + p01[r], s1 = p10[r] + p11[r];
@@ -1395,7 +1444,8 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
             };
             fetch(kv1, GT - 1, 1);
             GSTAMP(5);
-            for (int t = GT - 1; t >= (CLD_QDEBUG >= 2 ? GT - 1 : 0); --t) {
+            GPHASE_START;
+            for (int t = GT - 1; t >= 0; --t) {
                 // ---- layer 1 gate gradients -> LDS ----
 #pragma unroll
                 for (int aq = 0; aq < 2; ++aq) {
@@ -1410,16 +1460,17 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
                     row[192] = dh * tc * o_ * (1.f - o_);
                     dc1n[aq] = dc * f_;
                 }
+                GPHASE(6);
                 lds_barrier();
+                GPHASE(7);
                 fetch(kv0, t, 0);
                 v4f R0, R1;
                 tprodq(dG[0], t1, R0, R1);
+                GPHASE(8);
                 float down[2];
                 rec1[0] = pick(R0, src_rec); rec1[1] = pick(R1, src_rec);
                 down[0] = pick(R0, src_dwn); down[1] = pick(R1, src_dwn);
-#if CLD_QDEBUG == 3
-                for (int aq = 0; aq < 2; ++aq) { dz[4 * aq + q][u] = down[aq]; dz[4 * aq + q][64 + u] = rec1[aq]; }
-#endif
+                GPHASE(9);
                 // ---- layer 0 gate gradients -> LDS ----
 #pragma unroll
                 for (int aq = 0; aq < 2; ++aq) {
@@ -1434,23 +1485,24 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
                     row[192] = dh * tc * o_ * (1.f - o_);
                     dc0n[aq] = dc * f_;
                 }
+                GPHASE(10);
                 lds_barrier();
+                GPHASE(11);
                 if (t > 0) fetch(kv1, t - 1, 1);
                 tprodq(dG[1], t0, R0, R1);
+                GPHASE(12);
                 rec0[0] = pick(R0, src_rec); rec0[1] = pick(R1, src_rec);
-                // dL/dz_t, complete: result lanes (kh 0, product 1, unit quad 0, agent q) = lanes 16..19, register r = latent channel r
+                // dL/dz_t, complete: result lanes (kh 0, product 1, unit quad 0, column = latent channel q) = lanes 16..19, register r = agent r
                 if (wv == 0 && lane >= 16 && lane < 20) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { dz[q][4 * t + r] = R0[r]; dz[4 + q][4 * t + r] = R1[r]; }
+                    for (int r = 0; r < 4; ++r) { dz[r][4 * t + q] = R0[r]; dz[4 + r][4 * t + q] = R1[r]; }
                 }
+                GPHASE(13);
             }
         }
+            GPHASE_PRINT(14);
         __syncthreads();
         GSTAMP(6);
-#if CLD_QDEBUG == 2
-        for (int i = tid; i < AG * 104; i += 256) { const int ag = i / 104, c = i % 104; dz[ag][c] = dG[0][ag][c + 60]; dz[ag][104 + c] = dG[1][ag][c + 60]; }
-        __syncthreads();
-#endif
         // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
         for (int i = tid; i < AG * 208; i += 256) {
             const int ag = i / 208, r = i % 208, b = b0 + ag;
@@ -1474,6 +1526,310 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
     }
 }
 
+// =============================================================================================
+// The same 8-agent formulation with the K dimension of every product split between two waves
+// =============================================================================================
+// guide_quad_kernel is bound by ONE wave's instruction issue per SIMD: a 4x4x1 MFMA occupies the wave for ~8 cycles and every
+// other instruction adds its own issue cycles on top (measured, scripts/ubench/mfma_valu.hip: +4.6 cycles per plain VALU pair,
+// +10 per transcendental, whatever the number of waves -- this MFMA has no shadow to hide VALU work in), and its backward
+// weights (256 registers) live half in AGPRs, which costs a reload move for every other MFMA.  Here eight waves share the work:
+// waves wq and wq + 4 own the same 16 hidden units but each takes HALF of the K dimension of every product (so half the weight
+// registers: 100 forward, 128 backward, all in VGPRs at two waves per SIMD) and the cell updates of ONE agent quad (kp = wave
+// >> 2).  The partial sums of the quad a wave does not own go to its partner through LDS.  A step is two phases with one
+// barrier each -- forward: [cell updates: layer 0 of step t + 1 and layer 1 of step t] | [half sweeps: layer 0 of step t + 2
+// and layer 1 of step t + 1]; backward: [exchanges + gate gradients: layer 1 of step s - 1 and layer 0 of step s] | [half
+// products: layer 1 of step s - 1 and layer 0 of step s] -- the layer that depends on nothing but itself runs one step ahead.
+namespace gq2 {
+constexpr int AG = 8, HS = 68, GS = 260;
+constexpr int ACTS = GT * 2 * 5 * 512;       // floats of kept activations per workgroup: [t][layer][i f g o c][thread]
+}  // namespace gq2
+
+__global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
+    using namespace gq2;
+    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
+    __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
+    __shared__ __attribute__((aligned(16))) float zin[AG][208];
+    __shared__ __attribute__((aligned(16))) float condm[AG][256];
+    __shared__ __attribute__((aligned(16))) float hpart[4][AG][HS];     // cond2hidden: K-quarter partials
+    __shared__ __attribute__((aligned(16))) float xch[2][8][64][4];     // [layer][wave][lane]: partial sums for the partner wave's quad
+    __shared__ float actp[GT][2][4][AG];     // [step][output][unit group][agent]: partials of hid2act
+    __shared__ float act[2][GT][AG];         // (acceleration, yaw-rate), scaled
+    __shared__ float dact[AG][2][GT];
+    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
+    __shared__ float dz[AG][208];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wv8 & 3, kp = wv8 >> 2;          // unit group; K half = the agent quad whose cells this wave updates
+    const int ul = lane >> 2, q = lane & 3;         // MFMA lane roles: block ul; A row q (gate); B / D column q (agent of a quad)
+    const int u = 16 * wq + ul;                     // this lane's hidden unit; its cell: (u, agent 4 kp + q)
+    const int ao = 4 * kp + q;
+    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
+    auto none = [](int) {};
+
+    const int ngroups = (a.B + AG - 1) / AG;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int b0 = grp * AG;
+        const __amdgpu_buffer_rsrc_t keep = __builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * ACTS, 0, ACTS * 4, 0x00020000);
+        const int kvo = tid * 4;
+        auto kput = [&](int slot, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), keep, kvo, slot * 2048, 0); };
+        auto kget = [&](int slot) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(keep, kvo, slot * 2048, 0)); };
+        auto agent = [&](int ag) { return (b0 + ag < a.B) ? b0 + ag : a.B - 1; };      // tail slots replay the last agent; never stored
+        for (int i = tid; i < AG * 256; i += 512) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
+        for (int i = tid; i < AG * 208; i += 512) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
+        __syncthreads();
+        if (wv8 < 4) {   // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49): wave wv8 takes the K quarter 64 wv8 .. + 63 of all 64 units
+            const float* wr = w.w_c2h + (size_t)(4 * ul + q) * 256 + 64 * wv8;
+            asm volatile("" : "+v"(wr));
+            v4f p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const v4f wa = *reinterpret_cast<const v4f*>(wr + 4 * j);
+                const v4f ca = *reinterpret_cast<const v4f*>(&condm[q][64 * wv8 + 4 * j]);
+                const v4f cb = *reinterpret_cast<const v4f*>(&condm[4 + q][64 * wv8 + 4 * j]);
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    p0 = CLD_MFMA4(wa[e], ca[e], p0); p1 = CLD_MFMA4(wa[e], cb[e], p1);
+                    p2 = CLD_MFMA4(wa[e + 1], ca[e + 1], p2); p3 = CLD_MFMA4(wa[e + 1], cb[e + 1], p3);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {            // D lane (unit quad ul, agent q): register r = unit 4 ul + r
+                hpart[wv8][q][4 * ul + r] = p0[r] + p2[r];
+                hpart[wv8][4 + q][4 * ul + r] = p1[r] + p3[r];
+            }
+        }
+        __syncthreads();
+        {
+            const int ag = tid >> 6, uu = tid & 63;
+            const float v = w.b_c2h[uu] + hpart[0][ag][uu] + hpart[1][ag][uu] + hpart[2][ag][uu] + hpart[3][ag][uu];
+            hs[0][0][ag][uu] = v;
+            hs[1][0][ag][uu] = v;
+        }
+        float c0 = 0.f, c1 = 0.f;
+        GPHASE_DECL;
+        __syncthreads();
+        // ---------------- forward ----------------
+        {
+            // weights as B operands (columns = the four gates of this lane's unit): this wave's K half, one register per k
+            //   layer 0 (K = 4 + 64): kp 0: x_t (4) and h0 units 0..31;  kp 1: h0 units 32..63 (its group 0 carries zero weights)
+            //   layer 1 (K = 64 + 64): kp 0: W_ih1 (h0_t);               kp 1: W_hh1 (h1_{t-1})
+            const size_t row = (size_t)(64 * q + u);
+            const float *p0a = w.w_ih0 + row * 4, *p0b = w.w_hh0 + row * 64 + 32 * kp, *p1 = (kp ? w.w_hh1 : w.w_ih1) + row * 64, *p_b0 = w.b0 + u, *p_b1 = w.b1 + u;
+            asm volatile("" : "+v"(p0a), "+v"(p0b), "+v"(p1), "+v"(p_b0), "+v"(p_b1));
+            v4f W0[9], W1[16];
+            W0[0] = *reinterpret_cast<const v4f*>(p0a);
+            if (kp) W0[0] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) W0[1 + j] = *reinterpret_cast<const v4f*>(p0b + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) W1[j] = *reinterpret_cast<const v4f*>(p1 + 4 * j);
+            // biases: this lane's column is gate q of unit u; D register r = agent r of the quad; added once, by the kp 0 half
+            const float bq0 = kp ? 0.f : p_b0[64 * q], bq1 = kp ? 0.f : p_b1[64 * q];
+            const v4f bias0 = {bq0, bq0, bq0, bq0}, bias1 = {bq1, bq1, bq1, bq1};
+            const v4f zero = {0.f, 0.f, 0.f, 0.f};
+            v4f keep0, keep1;                 // this wave's half of its OWN quad's pre-activations (gate q x four agents)
+            // A operands: lane (block b, row q) reads agent 4 aq + q, k-group 8 kp + (b & 7) (layer 0: of the 16 groups of h0) or
+            // k-group b (layer 1: all 16 groups of the matrix this wave holds); see bsweep
+            auto half0 = [&](int t) {         // layer 0, step t: reads x_t and hs[0][t & 1]
+                const int pr = t & 1;
+                const v4f Xx[2] = {*reinterpret_cast<const v4f*>(&zin[q][4 * t]), *reinterpret_cast<const v4f*>(&zin[4 + q][4 * t])};
+                const v4f Xh[2] = {*reinterpret_cast<const v4f*>(&hs[0][pr][q][32 * kp + 4 * (ul & 7)]), *reinterpret_cast<const v4f*>(&hs[0][pr][4 + q][32 * kp + 4 * (ul & 7)])};
+                v4f a00 = bias0, a01 = zero, a10 = bias0, a11 = zero;
+                bsweep<0, 1, 4>(&Xx[0], &Xx[1], [&](int) { return W0[0]; }, a00, a01, a10, a11);
+                bsweep<0, 8, 4>(&Xh[0], &Xh[1], [&](int g) { return W0[1 + g]; }, a00, a01, a10, a11);
+                const v4f P0 = a00 + a01, P1 = a10 + a11;
+                *reinterpret_cast<v4f*>(&xch[0][wv8][lane][0]) = kp ? P0 : P1;      // the quad this wave does not own
+                keep0 = kp ? P1 : P0;
+            };
+            auto half1 = [&](int t) {         // layer 1, step t: kp 0 reads h0_t = hs[0][(t & 1) ^ 1], kp 1 reads h1_{t-1} = hs[1][t & 1]
+                const float* src = &hs[0][0][0][0] + (kp ? 2 * AG * HS + (t & 1) * AG * HS : ((t & 1) ^ 1) * AG * HS);
+                const v4f X[2] = {*reinterpret_cast<const v4f*>(src + q * HS + 4 * ul), *reinterpret_cast<const v4f*>(src + (4 + q) * HS + 4 * ul)};
+                v4f a00 = bias1, a01 = zero, a10 = bias1, a11 = zero;
+                bsweep<0, 16, 4>(&X[0], &X[1], [&](int g) { return W1[g]; }, a00, a01, a10, a11);
+                const v4f P0 = a00 + a01, P1 = a10 + a11;
+                *reinterpret_cast<v4f*>(&xch[1][wv8][lane][0]) = kp ? P0 : P1;
+                keep1 = kp ? P1 : P0;
+            };
+            auto cell0 = [&](int t) {
+                const v4f P = quad_transpose(keep0 + *reinterpret_cast<const v4f*>(&xch[0][wv8 ^ 4][lane][0]), q & 1, q & 2);   // -> agent q x four gates
+                const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
+                const float c = f_ * c0 + i_ * g_;
+                c0 = c;
+                hs[0][(t & 1) ^ 1][ao][u] = o_ * ftanh(c);
+                const int ks = (t * 2 + 0) * 5;      // slot of (step t, layer 0, gate 0); a slot = one float per thread
+                kput(ks + 0, i_); kput(ks + 1, f_); kput(ks + 2, g_); kput(ks + 3, o_); kput(ks + 4, c);
+            };
+            auto cell1 = [&](int t) {
+                const v4f P = quad_transpose(keep1 + *reinterpret_cast<const v4f*>(&xch[1][wv8 ^ 4][lane][0]), q & 1, q & 2);
+                const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
+                const float c = f_ * c1 + i_ * g_;
+                c1 = c;
+                const float hn = o_ * ftanh(c);
+                hs[1][(t & 1) ^ 1][ao][u] = hn;
+                const int ks = (t * 2 + 1) * 5;
+                kput(ks + 0, i_); kput(ks + 1, f_); kput(ks + 2, g_); kput(ks + 3, o_); kput(ks + 4, c);
+                float ap = hn * wa0, bp = hn * wa1;            // hid2act: partials over this wave's 16 units
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) { ap += __shfl_xor(ap, o); bp += __shfl_xor(bp, o); }
+                actp[t][0][wq][ao] = ap;                       // (the 16 lanes of a column hold the same sum)
+                actp[t][1][wq][ao] = bp;
+            };
+            half0(0);
+            lds_barrier();
+            cell0(0);
+            lds_barrier();
+            half0(1); half1(0);
+            lds_barrier();
+            GPHASE_START;
+            for (int t = 0; t < GT; ++t) {
+                if (t + 1 < GT) cell0(t + 1);
+                GPHASE(0);
+                cell1(t);
+                GPHASE(1);
+                lds_barrier();
+                GPHASE(2);
+                if (t + 2 < GT) half0(t + 2);
+                GPHASE(3);
+                if (t + 1 < GT) half1(t + 1);
+                GPHASE(4);
+                lds_barrier();
+                GPHASE(5);
+            }
+        }
+        // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
+        for (int i = tid; i < 2 * GT * AG; i += 512) {
+            const int o = i / (GT * AG), t = (i / AG) % GT, ag = i % AG;
+            act[o][t][ag] = (o ? bh2b : bh2a) + actp[t][o][0][ag] + actp[t][o][1][ag] + actp[t][o][2][ag] + actp[t][o][3][ag];
+        }
+        __syncthreads();
+        if (tid < AG)
+            chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
+        __syncthreads();
+        // ---------------- backward through time ----------------
+        {
+            // B operands of the products (DecoderWeights::gqfrag, see guide_quad_kernel): block = (K half kh, product m, unit quad ub);
+            // of the 32 k-groups of a lane this wave takes groups 16 kp .. 16 kp + 15, i.e. gate columns 128 kh + 64 kp + 4 g + e --
+            // the four K quarters are added across lanes l / l ^ 32 and across the two waves
+            const v4f* gf = reinterpret_cast<const v4f*>(w.gqfrag) + (size_t)wq * (2 * 32 * 64) + (size_t)kp * (16 * 64) + lane;
+            asm volatile("" : "+v"(gf));
+            v4f t1[16], t0[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { t1[j] = gf[j * 64]; t0[j] = gf[(32 + j) * 64]; }
+            const int kh = lane >> 5;
+            // owner lane (unit ul, agent q) <- result lane (kh 0, product m, unit quad ul >> 2, column ul & 3) = lane 16 m + ul, register q
+            const int src_rec = ul * 4, src_dwn = src_rec + 64, rsel = q, xor32 = (lane ^ 32) * 4;
+            auto pick = [&](const v4f& v, int byte_lane) {
+                const float x0 = bperm(byte_lane, v[0]), x1 = bperm(byte_lane, v[1]), x2 = bperm(byte_lane, v[2]), x3 = bperm(byte_lane, v[3]);
+                return rsel == 0 ? x0 : (rsel == 1 ? x1 : (rsel == 2 ? x2 : x3));
+            };
+            v4f keepS1 = {0.f, 0.f, 0.f, 0.f}, keepS0 = keepS1;
+            // half product of layer `lay` (0: gate gradients dG[0] of LSTM layer 1, 1: dG[1] of LSTM layer 0): K quarters of this lane
+            // and wave; the in-wave halves are added here, the partner's half in the exchange
+            auto halfprod = [&](int lay, const v4f (&tw)[16], v4f& keepS) {
+                // A operand: lane (kh, block b of the half, row q) reads the four columns of k-group 8 c + b of this wave's K quarter
+                const float* gq0 = &dG[lay][q][128 * kh + 64 * kp + 4 * (ul & 7)];
+                const float* gq1 = &dG[lay][4 + q][128 * kh + 64 * kp + 4 * (ul & 7)];
+                const v4f X0[2] = {*reinterpret_cast<const v4f*>(gq0), *reinterpret_cast<const v4f*>(gq0 + 32)};
+                const v4f X1[2] = {*reinterpret_cast<const v4f*>(gq1), *reinterpret_cast<const v4f*>(gq1 + 32)};
+                v4f p00 = {0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+                bsweep<0, 16, 3>(X0, X1, [&](int g) { return tw[g]; }, p00, p01, p10, p11);
+                v4f S0 = p00 + p01, S1 = p10 + p11;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { S0[r] += bperm(xor32, S0[r]); S1[r] += bperm(xor32, S1[r]); }
+                *reinterpret_cast<v4f*>(&xch[lay][wv8][lane][0]) = kp ? S0 : S1;
+                keepS = kp ? S1 : S0;
+            };
+            float rec1 = 0.f, rec0 = 0.f, down = 0.f, dc1n = 0.f, dc0n = 0.f;
+            float kv1[6], kv0[6];
+            auto fetch = [&](float (&kv)[6], int t, int layer) {
+                const int ks = (t * 2 + layer) * 5;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) kv[k] = kget(ks + k);
+                kv[5] = kget(ks - 10 + 4);      // the cell state of step t-1, same layer (t = 0: outside the buffer -> 0)
+            };
+            auto grads = [&](const float (&kv)[6], float dh, float& dcn, float* row) {
+                const float i_ = kv[0], f_ = kv[1], g_ = kv[2], o_ = kv[3], c = kv[4], cp = kv[5];
+                const float tc = ftanh(c);
+                const float dc = dh * o_ * (1.f - tc * tc) + dcn;
+                row[0] = dc * g_ * i_ * (1.f - i_);
+                row[64] = dc * cp * f_ * (1.f - f_);
+                row[128] = dc * i_ * (1.f - g_ * g_);
+                row[192] = dh * tc * o_ * (1.f - o_);
+                dcn = dc * f_;
+            };
+            auto grad1 = [&](int s) { grads(kv1, wa0 * dact[ao][0][s] + wa1 * dact[ao][1][s] + rec1, dc1n, &dG[0][ao][u]); };
+            auto grad0 = [&]() { grads(kv0, down + rec0, dc0n, &dG[1][ao][u]); };
+            auto xchg1 = [&]() {      // layer-1 product of step s complete -> rec1 (for step s - 1), down (for layer 0, step s)
+                const v4f S = keepS1 + *reinterpret_cast<const v4f*>(&xch[0][wv8 ^ 4][lane][0]);
+                rec1 = pick(S, src_rec);
+                down = pick(S, src_dwn);
+            };
+            auto xchg0 = [&](int s) { // layer-0 product of step s complete -> rec0 (for step s - 1), dL/dz_s
+                const v4f S = keepS0 + *reinterpret_cast<const v4f*>(&xch[1][wv8 ^ 4][lane][0]);
+                rec0 = pick(S, src_rec);
+                // dL/dz_s, complete: result lanes (kh 0, product 1, unit quad 0, column = latent channel q) = lanes 16..19, register r = agent r
+                if (wq == 0 && lane >= 16 && lane < 20) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz[4 * kp + r][4 * s + q] = S[r];
+                }
+            };
+            // prologue: layer 1 at the last step
+            fetch(kv1, GT - 1, 1);
+            fetch(kv0, GT - 1, 0);
+            grad1(GT - 1);
+            lds_barrier();
+            fetch(kv1, GT - 2, 1);
+            halfprod(0, t1, keepS1);
+            lds_barrier();
+            GPHASE_START;
+            for (int s = GT - 1; s >= 0; --s) {
+                // phase A: exchanges and gate gradients
+                xchg1();                                   // layer-1 product of step s
+                GPHASE(6);
+                if (s > 0) grad1(s - 1);
+                GPHASE(7);
+                if (s < GT - 1) xchg0(s + 1);              // layer-0 product of step s + 1
+                GPHASE(8);
+                grad0();                                   // layer 0, step s (kv0 = step s)
+                GPHASE(9);
+                lds_barrier();
+                GPHASE(10);
+                // phase B: half products
+                if (s > 1) fetch(kv1, s - 2, 1);
+                if (s > 0) fetch(kv0, s - 1, 0);
+                if (s > 0) halfprod(0, t1, keepS1);        // layer 1, step s - 1
+                GPHASE(11);
+                halfprod(1, t0, keepS0);                   // layer 0, step s
+                GPHASE(12);
+                lds_barrier();
+                GPHASE(13);
+            }
+            xchg0(0);
+            GPHASE_PRINT(14);
+        }
+        __syncthreads();
+        // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
+        for (int i = tid; i < AG * 208; i += 512) {
+            const int ag = i / 208, r = i % 208, b = b0 + ag;
+            if (b >= a.B) continue;
+            const float g = dz[ag][r];
+            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
+            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
+            const float mu = zin[ag][r] + delta;
+            if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
+            if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
+            if (a.x_out) {
+                float zz = 0.f;
+                if (a.sigma != 0.f) zz = a.z ? a.z[(size_t)b * 208 + r] : normal4(a.seed, a.step_salt, (unsigned)(b * 52 + (r >> 2)))[r & 3];
+                const float xn = mu + a.sigma * zz;
+                a.x_out[(size_t)b * 208 + r] = xn;
+                if (a.x_out2) a.x_out2[(size_t)b * 208 + r] = xn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int guide_mfma_grid(int B) {
     const int groups = (B + gm::AG - 1) / gm::AG;
     return groups < 256 ? groups : 256;
@@ -1482,20 +1838,22 @@ static int guide_quad_grid(int B) {
     const int groups = (B + gq::AG - 1) / gq::AG;
     return groups < 256 ? groups : 256;
 }
-// Which formulation by batch size.  The MFMA kernels need one workgroup per CU to fill the chip and each workgroup is bound by
-// its own MFMA issue, so what counts is the number of ROUNDS of workgroups over the 256 CUs: the 8-agent kernel (a round costs
-// ~0.6 of a 16-agent round) wins while it needs no more rounds than the 16-agent kernel would, i.e. up to 2,048 agents and
-// again wherever ceil(B / 2048) == ceil(B / 4096) fails to hold the other way; below 256 agents the 2-agent VALU kernel
-// (more workgroups) is faster.  Tests force each form through cld_debug_force_kernel.
+// Which formulation by batch size.  The MFMA kernels put one workgroup on a CU and each workgroup is bound by its own instruction
+// issue, so what counts is the number of ROUNDS of workgroups over the 256 CUs: the 8-agent kernel (a round costs ~0.67 of a
+// 16-agent round: 340 vs 506 us) wins whenever it needs fewer than 1.5 x the rounds of the 16-agent kernel -- up to 2,048 agents
+// (one round each), not from 2,049 to 4,096 (two rounds against one), ...; a single round of the 2-agent VALU kernel
+// (up to 512 agents) takes as long as a round of the 8-agent kernel (340 vs 326 us), so it only keeps the smallest batches.
+// Tests force each form through cld_debug_force_kernel.
 static int guide_form(int B, int form) {
     if (form != FORM_AUTO) return form;
-    if (B < 256) return FORM_VALU;
+    if (B < 64) return FORM_VALU;
     const int r8 = (B + 8 * 256 - 1) / (8 * 256), r16 = (B + 16 * 256 - 1) / (16 * 256);
-    return 3 * r8 <= 5 * r16 ? FORM_MFMA_QUAD : FORM_MFMA;
+    return 2 * r8 < 3 * r16 ? FORM_MFMA_QUAD2 : FORM_MFMA;
 }
 size_t guide_scratch_floats(int B) {
     const size_t valu = (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS);
     static_assert(gm::ACTS == gm8::ACTS, "both 16-agent MFMA formulations keep the same number of activations per workgroup");
+    static_assert(gq::ACTS == gq2::ACTS, "both 8-agent formulations keep the same number of activations per workgroup");
     const size_t mfma = (size_t)guide_mfma_grid(B) * gm::ACTS, quad = (size_t)guide_quad_grid(B) * gq::ACTS;
     return valu > mfma ? (valu > quad ? valu : quad) : (mfma > quad ? mfma : quad);
 }
@@ -1503,6 +1861,7 @@ size_t guide_scratch_floats(int B) {
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
     switch (guide_form(a.B, form)) {
         case FORM_MFMA_QUAD: hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(256), 0, s, w, d, a); break;
+        case FORM_MFMA_QUAD2: hipLaunchKernelGGL(guide_quad2_kernel, dim3(guide_quad_grid(a.B)), dim3(512), 0, s, w, d, a); break;
         case FORM_MFMA_4WAVE: hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a); break;
         case FORM_MFMA: hipLaunchKernelGGL(guide_mfma8_kernel, dim3(guide_mfma_grid(a.B)), dim3(512), 0, s, w, d, a); break;
         default: hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);

@@ -18,7 +18,7 @@ __global__ void layout(float* out) {     // out[3][64][4]
     for (int r = 0; r < 4; ++r) { out[(0 * 64 + l) * 4 + r] = d1[r]; out[(1 * 64 + l) * 4 + r] = d2[r]; out[(2 * 64 + l) * 4 + r] = d3[r]; }
 }
 
-template <int NACC>
+template <int NACC, int CB = 0>
 __global__ __launch_bounds__(256) void rate(float* out, unsigned long long* cyc, int iters) {
     const int l = threadIdx.x & 63;
     v4f acc[NACC];
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void rate(float* out, unsigned long long* cyc,
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[i], CB, CB ? 1 : 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -85,6 +85,7 @@ int main() {
         printf("%-22s %d accumulators: %6.2f cycles per MFMA per wave (one wave per SIMD) -> %5.1f FLOP/cycle/SIMD\n", nm, nacc, per, flop_per / per);
     };
     run(rate<1>, "4x4x1_16b", 1, 512.0); run(rate<2>, "4x4x1_16b", 2, 512.0); run(rate<4>, "4x4x1_16b", 4, 512.0); run(rate<8>, "4x4x1_16b", 8, 512.0);
+    run(rate<4, 4>, "4x4x1_16b cbsz=4", 4, 512.0); run(rate<4, 3>, "4x4x1_16b cbsz=3", 4, 512.0); run(rate<8, 4>, "4x4x1_16b cbsz=4", 8, 512.0);
     run(rate16<1>, "16x16x4", 1, 2048.0); run(rate16<4>, "16x16x4", 4, 2048.0);
     return 0;
 }
