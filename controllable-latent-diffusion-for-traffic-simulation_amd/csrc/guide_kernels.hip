@@ -1189,6 +1189,20 @@ __device__ __forceinline__ void bsweep(const v4f* X0, const v4f* X1, WF wt, v4f&
     }
 }
 
+// Sum over the 16 lanes that share (lane & 3) -- the 16 hidden units of a wave for one agent -- left in all of them: two DPP row
+// rotations inside the 16-lane rows, then the gfx950 row / half swaps (v_permlane16_swap, v_permlane32_swap: pure VALU, where
+// __shfl_xor by 16 and 32 goes through the LDS crossbar and costs ~100 cycles of latency each on a dependent chain).
+__device__ __forceinline__ float sum_over_units(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned a16 = r16[0], b16 = r16[1];      // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0, see bperm)
+    x = __builtin_bit_cast(float, a16) + __builtin_bit_cast(float, b16);      // rows 0 + 1 | rows 2 + 3
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned a32 = r32[0], b32 = r32[1];
+    return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);   // lower + upper half
+}
+
 // 4 x 4 transpose across the four lanes of a quad: out[g] = register (lane & 3) of the quad's lane g.  Two butterfly stages
 // (lane bit 0 with register bit 0, then bit 1 with bit 1), each one select for what to send, one DPP quad permute, two selects.
 __device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false)); }
@@ -1371,9 +1385,7 @@ __global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w,
                     aq_[aq] = hn * wa1;
                 }
 #pragma unroll
-                for (int o = 4; o < 64; o <<= 1)           // sum over the 16 units of the wave: lane bits 2..5
-#pragma unroll
-                    for (int aq = 0; aq < 2; ++aq) { ap[aq] += __shfl_xor(ap[aq], o); aq_[aq] += __shfl_xor(aq_[aq], o); }
+                for (int aq = 0; aq < 2; ++aq) { ap[aq] = sum_over_units(ap[aq]); aq_[aq] = sum_over_units(aq_[aq]); }
                 if (ul == 0) {
 #pragma unroll
                     for (int aq = 0; aq < 2; ++aq) { actp[pr][0][wv][4 * aq + q] = ap[aq]; actp[pr][1][wv][4 * aq + q] = aq_[aq]; }
@@ -1668,11 +1680,8 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
                 hs[1][(t & 1) ^ 1][ao][u] = hn;
                 const int ks = (t * 2 + 1) * 5;
                 kput(ks + 0, i_); kput(ks + 1, f_); kput(ks + 2, g_); kput(ks + 3, o_); kput(ks + 4, c);
-                float ap = hn * wa0, bp = hn * wa1;            // hid2act: partials over this wave's 16 units
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) { ap += __shfl_xor(ap, o); bp += __shfl_xor(bp, o); }
-                actp[t][0][wq][ao] = ap;                       // (the 16 lanes of a column hold the same sum)
-                actp[t][1][wq][ao] = bp;
+                actp[t][0][wq][ao] = sum_over_units(hn * wa0);      // hid2act: partials over this wave's 16 units
+                actp[t][1][wq][ao] = sum_over_units(hn * wa1);      // (the 16 lanes of a column hold the same sum)
             };
             half0(0);
             lds_barrier();
