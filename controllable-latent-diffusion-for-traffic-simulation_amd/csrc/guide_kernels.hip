@@ -168,6 +168,242 @@ __device__ __forceinline__ void chain_grad(const DynParams& d, const GuideArgs& 
     }
 }
 
+// The same function for the AGN agents of a workgroup, by all NT threads of it.  chain_grad is one thread per agent walking the
+// 52 steps twice with a sine / cosine pair, divisions and branches at every step: 55k cycles on 8 lanes while the other waves
+// wait (6 % of an 8-agent guided step).  Everything in it that is elementwise in (agent, step) runs here one (agent, step)
+// pair per thread; what remains sequential are six running sums over the steps, done by one lane per agent in the original
+// order of additions -- so the results are those of chain_grad, sum for sum (the loss terms have kinks -- |v - target|, the
+// clips -- where a re-associated sum could flip a sign).  Phases alternate, one __syncthreads between them.
+// sc: CG_ROWS x 54 floats per agent.  act / dact as in chain_grad (act0 / act1 [t * st + agent], dact [agent][2][GT]).
+constexpr int CG_ROWS = 16;
+template <int AGN, int NT, class AgentFn>
+__device__ __forceinline__ void chain_grad_group(const DynParams& d, const GuideArgs& a, AgentFn agent, const float* act0, const float* act1, int st,
+                                                 float* dact, float* sc_all) {
+    const int tid = threadIdx.x;
+    enum { VK = 0, TH = 1, GV = 2, MASK = 3, GXK = 4, GYK = 5, ACCC = 6, WC = 7, CX = 8, CY = 9, DTH = 10, DVBAR = 11, THS = 12, DVY = 13, DVK1 = 14, RUN = 15 };
+    auto row = [&](int ag, int r) { return sc_all + (ag * CG_ROWS + r) * 54; };
+    // per-thread view of its (agent, step) pair(s) and of the agent's constants
+    struct Consts { const float* cs; const float* tgt; const float* eg; float s_ts, s_sl, s_al, s_tp; bool pos; };
+    auto consts = [&](int ag) {
+        const int b = agent(ag);
+        Consts c;
+        c.cs = a.curr_states + (size_t)b * 4;
+        c.tgt = a.target_speed ? a.target_speed + (size_t)b * GT : nullptr;
+        c.s_ts = c.tgt ? (a.loss_scale ? a.loss_scale[b] : (1.0f / (float)GT)) : 0.f;
+        c.s_sl = a.speed_limit_scale ? a.speed_limit_scale[b] : 0.f;
+        c.s_al = a.acc_limit_scale ? a.acc_limit_scale[b] : 0.f;
+        c.s_tp = a.target_pos_scale ? a.target_pos_scale[b] : 0.f;
+        c.eg = a.ext_grad ? a.ext_grad + (size_t)b * GT * 6 : nullptr;
+        c.pos = c.s_tp != 0.f || c.eg != nullptr;
+        return c;
+    };
+    // ---- P1: clipped accelerations ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, t = i % GT;
+        const float acc = act0[t * st + ag] * d.std[4] + d.mean[4];
+        row(ag, ACCC)[t] = fminf(fmaxf(acc, d.acc_lo), d.acc_hi);
+    }
+    __syncthreads();
+    // ---- S1: speeds (running sum) ----
+    if (tid < AGN) {
+        const int ag = tid;
+        const float* cs = a.curr_states + (size_t)agent(ag) * 4;
+        float* vk = row(ag, VK); float* mk = row(ag, MASK); const float* ac = row(ag, ACCC);
+        float v_raw = cs[2];
+        vk[0] = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
+        for (int t = 0; t < GT; ++t) {
+            v_raw += ac[t] * d.dt;
+            mk[t + 1] = (v_raw >= d.v_lo && v_raw <= d.v_hi) ? 1.f : 0.f;
+            vk[t + 1] = fminf(fmaxf(v_raw, d.v_lo), d.v_hi);
+        }
+    }
+    __syncthreads();
+    // ---- P2: direct loss terms on v_{t+1}; clipped yaw rates ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, t = i % GT;
+        const Consts c = consts(ag);
+        const float* vk = row(ag, VK);
+        const float v = vk[t + 1];
+        float g = 0.f;
+        if (c.tgt) {
+            const float df = v - c.tgt[t];
+            g += c.s_ts * ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));        // d|x|/dx, 0 at 0 (and for NaN targets: nan_to_num)
+        }
+        if (c.s_sl != 0.f && fabsf(v) - a.speed_limit > 0.f) g += c.s_sl * ((v > 0.f) ? 1.f : -1.f);
+        if (c.eg) g += c.eg[t * 6 + 2];
+        row(ag, GV)[t + 1] = g;
+        if (t == 0) { row(ag, GV)[0] = 0.f; row(ag, DVBAR)[GT] = 0.f; row(ag, DVY)[GT] = 0.f; }
+        if (c.pos) {
+            const float av = fabsf(vk[t]);
+            const float yb = fmaxf(fminf(d.max_steer * av, d.max_yawvel / fmaxf(av, 0.1f)), 0.1f);
+            const float wr = act1[t * st + ag] * d.std[5] + d.mean[5];
+            row(ag, WC)[t] = fmaxf(fminf(wr, yb), -yb);
+        }
+    }
+    __syncthreads();
+    // ---- S2: headings (running sum) ----
+    if (tid < AGN) {
+        const int ag = tid;
+        const Consts c = consts(ag);
+        if (c.pos) {
+            float* th = row(ag, TH); const float* wc = row(ag, WC);
+            float yaw = c.cs[3];
+            th[0] = yaw;
+            for (int t = 0; t < GT; ++t) { yaw += wc[t] * d.dt; th[t + 1] = yaw; }
+        }
+    }
+    __syncthreads();
+    // ---- P3: displacement terms ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, t = i % GT;
+        const Consts c = consts(ag);
+        if (c.pos) {
+            const float* vk = row(ag, VK);
+            const float vbar = 0.5f * (vk[t] + vk[t + 1]);
+            const float yaw = row(ag, TH)[t];
+            row(ag, CX)[t] = vbar * cosf(yaw);
+            row(ag, CY)[t] = vbar * sinf(yaw);
+        }
+    }
+    __syncthreads();
+    // ---- S3: positions (running sums), the position losses on them, and the suffix sums of dL/dx, dL/dy ----
+    if (tid < AGN) {
+        const int ag = tid, b = agent(ag);
+        const Consts c = consts(ag);
+        float* gxk = row(ag, GXK); float* gyk = row(ag, GYK);
+        if (c.pos) {
+            const float* cx = row(ag, CX); const float* cy = row(ag, CY);
+            float x = c.cs[0], y = c.cs[1];
+            for (int t = 0; t < GT; ++t) { x += cx[t] * d.dt; y += cy[t] * d.dt; gxk[t] = x; gyk[t] = y; }
+            if (c.s_tp == 0.f) {
+                for (int t = 0; t < GT; ++t) { gxk[t] = 0.f; gyk[t] = 0.f; }
+            } else {      // positions -> direct position gradients (as in chain_grad)
+                int tstar = a.target_time[b]; tstar = tstar > GT - 1 ? GT - 1 : tstar;
+                const float wx = a.target_pos[2 * b], wy = a.target_pos[2 * b + 1];
+                if (tstar >= 0) {
+                    const float ex = gxk[tstar] - wx, ey = gyk[tstar] - wy;
+                    const float nrm = sqrtf(ex * ex + ey * ey);
+                    for (int t = 0; t < GT; ++t) { gxk[t] = 0.f; gyk[t] = 0.f; }
+                    if (nrm > 0.f) { gxk[tstar] = c.s_tp * ex / nrm; gyk[tstar] = c.s_tp * ey / nrm; }
+                } else {
+                    int m = -tstar - 1;
+                    m = m > GT - 1 ? GT - 1 : m;
+                    float dmin = 3.4e38f;
+                    for (int t = m; t < GT; ++t) {
+                        const float ex = gxk[t] - wx, ey = gyk[t] - wy;
+                        dmin = fminf(dmin, sqrtf(ex * ex + ey * ey));
+                    }
+                    float z = 0.f, S = 0.f;
+                    for (int t = m; t < GT; ++t) {
+                        const float ex = gxk[t] - wx, ey = gyk[t] - wy;
+                        const float dd = sqrtf(ex * ex + ey * ey), e = expf(-(dd - dmin));
+                        z += e; S += e * dd * dd;
+                    }
+                    S /= z;
+                    const float inv = c.s_tp / (float)(GT - m);
+                    for (int t = 0; t < GT; ++t) {
+                        if (t < m) { gxk[t] = 0.f; gyk[t] = 0.f; continue; }
+                        const float ex = gxk[t] - wx, ey = gyk[t] - wy;
+                        const float dd = sqrtf(ex * ex + ey * ey), wgt = expf(-(dd - dmin)) / z;
+                        const float k = inv * wgt * (2.f + (dd > 0.f ? (S - dd * dd) / dd : 0.f));
+                        gxk[t] = k * ex; gyk[t] = k * ey;
+                    }
+                }
+            }
+            float gx = 0.f, gy = 0.f;           // dL/dx_{k+1}, dL/dy_{k+1} summed over the steps >= k
+            for (int k = GT - 1; k >= 0; --k) {
+                gx += gxk[k]; gy += gyk[k];
+                if (c.eg) { gx += c.eg[k * 6 + 0]; gy += c.eg[k * 6 + 1]; }
+                gxk[k] = gx; gyk[k] = gy;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P5: dL/dvbar_k and dL/dth_k through the positions ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, k = i % GT;
+        const Consts c = consts(ag);
+        if (c.pos) {
+            const float* vk = row(ag, VK);
+            float sn, cn;
+            sincosf(row(ag, TH)[k], &sn, &cn);
+            const float vbar = 0.5f * (vk[k] + vk[k + 1]);
+            const float gx = row(ag, GXK)[k], gy = row(ag, GYK)[k];
+            row(ag, DVBAR)[k] = d.dt * (gx * cn + gy * sn);
+            row(ag, DTH)[k] = d.dt * vbar * (-gx * sn + gy * cn);
+        } else {
+            row(ag, DVBAR)[k] = 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- S5: suffix sums of dL/dth ----
+    if (tid < AGN) {
+        const int ag = tid;
+        const Consts c = consts(ag);
+        if (c.pos) {
+            const float* dth = row(ag, DTH); float* ths = row(ag, THS);
+            float g = 0.f;                      // sum_{m > k} dL/dth_m (+ the direct terms on th_{m}, m > k)
+            for (int k = GT - 1; k >= 0; --k) {
+                if (c.eg) g += c.eg[k * 6 + 3];
+                ths[k] = g;
+                g += dth[k];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- P6: the yaw-rate clip: dL/d yaw-rate action, and the part of it routed into v_k through the bound ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, k = i % GT;
+        const Consts c = consts(ag);
+        float d_w = 0.f, d_vk_from_yb = 0.f;
+        if (c.pos) {
+            const float* vk = row(ag, VK);
+            const float d_wc = d.dt * row(ag, THS)[k];
+            const float av = fabsf(vk[k]);
+            const float ya = d.max_steer * av, ybb = d.max_yawvel / fmaxf(av, 0.1f);
+            const float yb = fmaxf(fminf(ya, ybb), 0.1f);
+            const float wr = act1[k * st + ag] * d.std[5] + d.mean[5];
+            float d_yb = 0.f;
+            if (wr > yb) d_yb = d_wc; else if (wr < -yb) d_yb = -d_wc; else d_w = d_wc;
+            if (c.eg) d_w += c.eg[k * 6 + 5];
+            if (d_yb != 0.f && fminf(ya, ybb) > 0.1f) {
+                const float dyb_dav = (ya < ybb) ? d.max_steer : ((av > 0.1f) ? -d.max_yawvel / (av * av) : 0.f);
+                d_vk_from_yb = d_yb * dyb_dav * ((vk[k] > 0.f) ? 1.f : ((vk[k] < 0.f) ? -1.f : 0.f));
+            }
+        }
+        row(ag, DVY)[k] = d_vk_from_yb;
+        dact[(ag * 2 + 1) * GT + k] = d_w * d.std[5];
+    }
+    __syncthreads();
+    // ---- P7: dL/dv_{k+1}: direct terms + the yaw-bound path + both averages it enters ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, k = i % GT;
+        const float* dvb = row(ag, DVBAR);
+        const float gvn = row(ag, GV)[k + 1] + row(ag, DVY)[k + 1];
+        row(ag, DVK1)[k] = (gvn + 0.5f * (dvb[k] + dvb[k + 1])) * row(ag, MASK)[k + 1];
+    }
+    __syncthreads();
+    // ---- S6: suffix sums of dL/dv_raw ----
+    if (tid < AGN) {
+        const int ag = tid;
+        const float* dv = row(ag, DVK1); float* rn = row(ag, RUN);
+        float run = 0.f;
+        for (int k = GT - 1; k >= 0; --k) { run += dv[k]; rn[k] = run; }
+    }
+    __syncthreads();
+    // ---- P8: dL/d acceleration action ----
+    for (int i = tid; i < AGN * GT; i += NT) {
+        const int ag = i / GT, k = i % GT;
+        const Consts c = consts(ag);
+        const float acc = act0[k * st + ag] * d.std[4] + d.mean[4];
+        float g = (acc >= d.acc_lo && acc <= d.acc_hi) ? row(ag, RUN)[k] * d.dt : 0.f;
+        if (c.s_al != 0.f && fabsf(acc) - a.acc_limit > 0.f) g += c.s_al * ((acc > 0.f) ? 1.f : -1.f);
+        if (c.eg) g += c.eg[k * 6 + 4];
+        dact[(ag * 2 + 0) * GT + k] = g * d.std[4];
+    }
+    __syncthreads();
+}
+
 constexpr int G_GATES = GT * 2 * 256;        // floats: post-activation gates [t][layer][256]
 constexpr int G_CELLS = GT * 2 * 64;         // floats: cell states [t][layer][64]
 constexpr int GNA = 2;                       // agents per workgroup: the register-resident weights are reused across them
@@ -1567,7 +1803,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
     __shared__ float actp[GT][2][4][AG];     // [step][output][unit group][agent]: partials of hid2act
     __shared__ float act[2][GT][AG];         // (acceleration, yaw-rate), scaled
     __shared__ float dact[AG][2][GT];
-    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
+    __shared__ float chs[AG][CG_ROWS * 54];  // roll-out scratch of chain_grad_group
     __shared__ float dz[AG][208];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1711,9 +1947,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
             act[o][t][ag] = (o ? bh2b : bh2a) + actp[t][o][0][ag] + actp[t][o][1][ag] + actp[t][o][2][ag] + actp[t][o][3][ag];
         }
         __syncthreads();
-        if (tid < AG)
-            chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
-        __syncthreads();
+        chain_grad_group<AG, 512>(d, a, agent, &act[0][0][0], &act[1][0][0], AG, &dact[0][0][0], &chs[0][0]);
         // ---------------- backward through time ----------------
         {
             // B operands of the products (DecoderWeights::gqfrag, see guide_quad_kernel): block = (K half kh, product m, unit quad ub);
