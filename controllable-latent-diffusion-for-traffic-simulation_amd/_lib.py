@@ -31,7 +31,7 @@ class CldConfig(C.Structure):
 PRECISIONS = {"f32": 0, "f16x2": 1}
 OPTIMIZERS = {"adam": 0, "sgd": 1}
 KERNELS = {"guide": 0, "decode": 1, "encode": 2}        # cld_debug_force_kernel
-FORMS = {"auto": 0, "valu": 1, "mfma": 2, "mfma4": 3, "quad": 4, "quad2": 5}        # 3..5: guide kernel only
+FORMS = {"auto": 0, "valu": 1, "mfma": 2, "quad": 3}        # "quad": guide kernel only
 
 
 class CldGuidance(C.Structure):

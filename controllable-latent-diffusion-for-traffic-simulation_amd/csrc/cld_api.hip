@@ -577,7 +577,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 2 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 5 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 2 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }
@@ -842,7 +842,7 @@ int cld_finalize(cld_handle h, void* stream) {
                                 g[o++] = v;
                             }
             UP(tmp, g); h->dec.gfrag = tmp;
-            // A operands of the backward products of guide_quad_kernel: wave wv owns units 16 wv .. 16 wv + 15; lane = 4 block + row,
+            // B operands of the backward products of guide_quad_kernel: waves wv and wv + 4 own units 16 wv .. 16 wv + 15; lane = 4 block + column,
             // block = (K half kh << 3) | (product m << 2) | unit quad ub; k-step (j, e) is gate column col = 128 kh + 4 j + e;
             // layer 1 (first): m = 0 -> W_hh1[col][16 wv + 4 ub + row], m = 1 -> W_ih1[col][same];
             // layer 0: m = 0 -> W_hh0[col][same], m = 1 and ub = 0 -> W_ih0[col][latent channel row], else 0

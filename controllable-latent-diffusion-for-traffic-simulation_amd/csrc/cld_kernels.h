@@ -125,7 +125,7 @@ struct DecoderWeights {   // device pointers, reference layouts
     const float *w_h2a, *b_h2a;        // [2,64] [2]
     // re-layouts made at cld_finalize for the MFMA guidance kernel (null when the decoder is absent):
     const float* gfrag;                // [wave 8][tile 2][k-group 16][lane 64][4]: B fragments of the transposed (backward) products
-    const float* gqfrag;               // [wave 4][layer 2][k-group 32][lane 64][4]: A operands of guide_quad_kernel's backward products
+    const float* gqfrag;               // [unit group 4][layer 2][k-group 32][lane 64][4]: B operands of guide_quad_kernel's backward products
 };
 struct DynParams {
     float dt, acc_lo, acc_hi, v_lo, v_hi, max_steer, max_yawvel;
@@ -133,9 +133,7 @@ struct DynParams {
 };
 // Kernel formulation of the three recurrent kernels (decode / encode / guide): picked by batch size unless a test forces one
 // through cld_debug_force_kernel.
-enum { FORM_AUTO = 0, FORM_VALU = 1, FORM_MFMA = 2, FORM_MFMA_4WAVE = 3 /* guide kernel only: the one-wave-per-SIMD MFMA form, kept for A/B */,
-       FORM_MFMA_QUAD = 4 /* guide kernel only: 8 agents per workgroup on the 4x4x1 MFMA */,
-       FORM_MFMA_QUAD2 = 5 /* guide kernel only: the same with K split between two waves per SIMD */ };
+enum { FORM_AUTO = 0, FORM_VALU = 1, FORM_MFMA = 2, FORM_MFMA_QUAD = 3 /* guide kernel only: 8 agents per workgroup on the 4x4x1 MFMA */ };
 // z [B,52,4], cond [B,256] -> act [B,52,2] (optional) ; if cs != null also traj [B,52,6]
 hipError_t launch_decode(const DecoderWeights& w, const DynParams& d, const float* z, const float* cond,
                          const float* cs, float* act, float* traj, int B, int descaled_output, hipStream_t s, int form = FORM_AUTO);

@@ -683,310 +683,18 @@ static int guide_grid(int B) {
     return groups < 512 ? groups : 512;
 }
 
-// =============================================================================================
-// MFMA formulation: 16 agents per workgroup, the recurrent products as v_mfma_f32_16x16x4_f32 tiles
-// =============================================================================================
-// Wave w owns hidden units 16w..16w+15 of BOTH layers.  For a layer step the gate pre-activations of 16 agents are the
-// GEMM [16 agents x K] x [K x 256]; wave w computes the four 16-column N-tiles {i, f, g, o} of ITS units, so the MFMA
-// result layout (lane = (unit n, agent block rb), 4 registers = agents 4rb..4rb+3) already holds all four gates of one
-// (agent, unit) cell in one lane: the cell update runs in registers and only h goes through LDS (the A operand of the next
-// product) -- two barriers per time step.  The backward products dG x W ([16 x 256] x [256 x 64]) come out in the same
-// layout, so the recurrent gradients stay in registers too; only the gate gradients pass through LDS.
-// A operands are read as float4 (4 consecutive k per lane, element e feeds MFMA e), B fragments use the same k permutation.
-namespace gm {
-constexpr int AG = 16;                  // agents per workgroup
-constexpr int HS = 68;                  // LDS row stride of the h tiles (68 / 4 odd: conflict-free b128 rows)
-constexpr int GS = 260;                 // LDS row stride of the gate-gradient tiles
-constexpr int ACTS = GT * 2 * 5 * 4 * 256;   // floats of kept activations per workgroup: [t][layer][i f g o c][r][thread]
-}  // namespace gm
-
 __device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-__global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
-    using namespace gm;
-    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
-    __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
-    __shared__ __attribute__((aligned(16))) float zin[AG][208];
-    __shared__ __attribute__((aligned(16))) float condm[AG][256];
-    __shared__ float actp[2][GT][4][AG];     // per-wave partials of the (acceleration, yaw-rate) output
-    __shared__ float dact[AG][2][GT];
-    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
-    __shared__ float dzp[2][4][AG][4];       // per-wave partials of dL/dz_t, by step parity
-    __shared__ float dz[AG][208];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, rb = lane >> 4;        // MFMA layouts: A lane = (row n, k kk = rb); B lane = (col n, k rb); D lane = (col n, rows 4rb..4rb+3)
-    const int u = 16 * wv + n;                      // this lane's hidden unit
-    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
-
-    const int ngroups = (a.B + AG - 1) / AG;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int b0 = grp * AG;
-        float* keep = a.scratch + (size_t)blockIdx.x * ACTS;
-        auto agent = [&](int ag) { return (b0 + ag < a.B) ? b0 + ag : a.B - 1; };      // tail slots replay the last agent; never stored
-        for (int i = tid; i < AG * 256; i += 256) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
-        for (int i = tid; i < AG * 208; i += 256) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
-        __syncthreads();
-        for (int i = tid; i < AG * 64; i += 256) {      // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49)
-            const int ag = i >> 6, uu = i & 63;
-            float s = w.b_c2h[uu];
-            const float* wr = w.w_c2h + uu * 256;
-            for (int k = 0; k < 256; ++k) s = fmaf(condm[ag][k], wr[k], s);
-            hs[0][0][ag][uu] = s;
-            hs[1][0][ag][uu] = s;
-        }
-        float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-        // ---------------- forward ----------------
-        {
-            int nn = n;
-            asm volatile("" : "+v"(nn));       // keeps the weight loads of this phase inside the group loop (see guide_kernel)
-            // B fragments: gate g', k-step (j, e) -> W[col = 64 g' + 16 wv + n][k = 16 j + 4 rb + e]
-            float f_hh0[4][4][4], f_ih1[4][4][4], f_hh1[4][4][4], f_ih0[4], fb0[4], fb1[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = 64 * g + 16 * wv + nn;
-                f_ih0[g] = w.w_ih0[col * 4 + rb];
-                fb0[g] = w.b0[col];
-                fb1[g] = w.b1[col];
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = 64 * g + 16 * wv + nn;
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const v4f x0 = *reinterpret_cast<const v4f*>(w.w_hh0 + col * 64 + 16 * jj + 4 * rb);
-                    const v4f x1 = *reinterpret_cast<const v4f*>(w.w_ih1 + col * 64 + 16 * jj + 4 * rb);
-                    const v4f x2 = *reinterpret_cast<const v4f*>(w.w_hh1 + col * 64 + 16 * jj + 4 * rb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { f_hh0[g][jj][e] = x0[e]; f_ih1[g][jj][e] = x1[e]; f_hh1[g][jj][e] = x2[e]; }
-                }
-            }
-            for (int t = 0; t < GT; ++t) {
-                const int pr = t & 1;
-                // ---- layer 0: pre = b + x_t W_ih0^T + h0_{t-1} W_hh0^T ----
-                v4f acc[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = v4f{fb0[g], fb0[g], fb0[g], fb0[g]};
-                {
-                    const float xa = zin[n][4 * t + rb];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, f_ih0[g], acc[g], 0, 0, 0);
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr][n][16 * jj + 4 * rb]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_hh0[g][jj][e], acc[g], 0, 0, 0);
-                }
-                float* kp = keep + (size_t)(t * 2 + 0) * (5 * 4 * 256) + tid;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ig = fsig(acc[0][r]), fg = fsig(acc[1][r]), gg = ftanh(acc[2][r]), og = fsig(acc[3][r]);
-                    const float c = fg * c0[r] + ig * gg;
-                    c0[r] = c;
-                    hs[0][pr ^ 1][4 * rb + r][u] = og * ftanh(c);
-                    kp[(0 * 4 + r) * 256] = ig; kp[(1 * 4 + r) * 256] = fg; kp[(2 * 4 + r) * 256] = gg; kp[(3 * 4 + r) * 256] = og;
-                    kp[(4 * 4 + r) * 256] = c;
-                }
-                __syncthreads();
-                // ---- layer 1: pre = b + h0_t W_ih1^T + h1_{t-1} W_hh1^T ----
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = v4f{fb1[g], fb1[g], fb1[g], fb1[g]};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const v4f ha = *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][n][16 * jj + 4 * rb]);
-                    const v4f hb = *reinterpret_cast<const v4f*>(&hs[1][pr][n][16 * jj + 4 * rb]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {      // the four gate accumulators in turn: no back-to-back dependent MFMAs
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[e], f_ih1[g][jj][e], acc[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hb[e], f_hh1[g][jj][e], acc[g], 0, 0, 0);
-                    }
-                }
-                kp += 5 * 4 * 256;
-                float ap[4], aq[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ig = fsig(acc[0][r]), fg = fsig(acc[1][r]), gg = ftanh(acc[2][r]), og = fsig(acc[3][r]);
-                    const float c = fg * c1[r] + ig * gg;
-                    c1[r] = c;
-                    const float hn = og * ftanh(c);
-                    hs[1][pr ^ 1][4 * rb + r][u] = hn;
-                    kp[(0 * 4 + r) * 256] = ig; kp[(1 * 4 + r) * 256] = fg; kp[(2 * 4 + r) * 256] = gg; kp[(3 * 4 + r) * 256] = og;
-                    kp[(4 * 4 + r) * 256] = c;
-                    ap[r] = hn * wa0;                       // hid2act: partials over this wave's 16 units
-                    aq[r] = hn * wa1;
-                }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { ap[r] += __shfl_xor(ap[r], o); aq[r] += __shfl_xor(aq[r], o); }
-                if (n == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { actp[0][t][wv][4 * rb + r] = ap[r]; actp[1][t][wv][4 * rb + r] = aq[r]; }
-                }
-                __syncthreads();
-            }
-        }
-        // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
-        if (tid < AG) {
-            for (int t = 0; t < GT; ++t) {
-                actp[0][t][0][tid] = actp[0][t][0][tid] + actp[0][t][1][tid] + actp[0][t][2][tid] + actp[0][t][3][tid] + bh2a;
-                actp[1][t][0][tid] = actp[1][t][0][tid] + actp[1][t][1][tid] + actp[1][t][2][tid] + actp[1][t][3][tid] + bh2b;
-            }
-            chain_grad(d, a, agent(tid), &actp[0][0][0][tid], &actp[1][0][0][tid], 4 * AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
-        }
-        __syncthreads();
-        // ---------------- backward through time ----------------
-        {
-            int nn = n;
-            asm volatile("" : "+v"(nn));
-            // B fragments of the transposed products: k-step (j, e) -> gate column col = 16 j + 4 rb + e, output unit 16 wv + n
-            float t_hh1[16][4], t_ih1[16][4], t_hh0[16][4], t_ih0[4][4];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int col = 16 * jj + 4 * rb + e;
-                    t_hh1[jj][e] = w.w_hh1[col * 64 + 16 * wv + nn];
-                    t_ih1[jj][e] = w.w_ih1[col * 64 + 16 * wv + nn];
-                    t_hh0[jj][e] = w.w_hh0[col * 64 + 16 * wv + nn];
-                }
-#pragma unroll
-            for (int jq = 0; jq < 4; ++jq)        // dL/dz: wave wv reduces gate columns 64 wv .. 64 wv + 63 (N = 4 latent channels, padded)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t_ih0[jq][e] = nn < 4 ? w.w_ih0[(64 * wv + 16 * jq + 4 * rb + e) * 4 + nn] : 0.f;
-            float rec1[4] = {0.f, 0.f, 0.f, 0.f}, rec0[4] = {0.f, 0.f, 0.f, 0.f};
-            float dc1n[4] = {0.f, 0.f, 0.f, 0.f}, dc0n[4] = {0.f, 0.f, 0.f, 0.f};
-            // kept activations of one (step, layer): i f g o c of 4 agents + the previous cell state; fetched from the
-            // L2-resident scratch one phase ahead, in flight under the MFMA block that precedes their use
-            float kv1[6][4], kv0[6][4];
-            auto fetch = [&](float (&kv)[6][4], int t, int layer) {
-                const float* kp = keep + (size_t)(t * 2 + layer) * (5 * 4 * 256) + tid;
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) kv[q][r] = kp[(q * 4 + r) * 256];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) kv[5][r] = t > 0 ? kp[(4 * 4 + r) * 256 - 2 * (5 * 4 * 256)] : 0.f;
-            };
-            fetch(kv1, GT - 1, 1);
-            for (int t = GT - 1; t >= 0; --t) {
-                // ---- layer 1 gate gradients -> LDS ----
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ig = kv1[0][r], fg = kv1[1][r], gg = kv1[2][r], og = kv1[3][r], c = kv1[4][r], cp = kv1[5][r];
-                    const float tc = ftanh(c);
-                    const float dh = wa0 * dact[4 * rb + r][0][t] + wa1 * dact[4 * rb + r][1][t] + rec1[r];
-                    const float dc = dh * og * (1.f - tc * tc) + dc1n[r];
-                    float* row = &dG[0][4 * rb + r][u];
-                    row[0] = dc * gg * ig * (1.f - ig);
-                    row[64] = dc * cp * fg * (1.f - fg);
-                    row[128] = dc * ig * (1.f - gg * gg);
-                    row[192] = dh * tc * og * (1.f - og);
-                    dc1n[r] = dc * fg;
-                }
-                __syncthreads();
-                fetch(kv0, t, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                v4f pa = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    const v4f ga = *reinterpret_cast<const v4f*>(&dG[0][n][16 * jj + 4 * rb]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        pa = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_hh1[jj][e], pa, 0, 0, 0);     // -> rec1 of step t-1
-                        pb = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_ih1[jj][e], pb, 0, 0, 0);     // -> dL/dh0_t from layer 1
-                    }
-                }
-                // ---- layer 0 gate gradients -> LDS ----
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    rec1[r] = pa[r];
-                    const float ig = kv0[0][r], fg = kv0[1][r], gg = kv0[2][r], og = kv0[3][r], c = kv0[4][r], cp = kv0[5][r];
-                    const float tc = ftanh(c);
-                    const float dh = pb[r] + rec0[r];
-                    const float dc = dh * og * (1.f - tc * tc) + dc0n[r];
-                    float* row = &dG[1][4 * rb + r][u];
-                    row[0] = dc * gg * ig * (1.f - ig);
-                    row[64] = dc * cp * fg * (1.f - fg);
-                    row[128] = dc * ig * (1.f - gg * gg);
-                    row[192] = dh * tc * og * (1.f - og);
-                    dc0n[r] = dc * fg;
-                }
-                __syncthreads();
-                if (t > 0) fetch(kv1, t - 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                // three accumulators in turn (two halves of the recurrent product + the dL/dz product): a lone accumulator would
-                // make every MFMA wait for its predecessor
-                v4f pc = {0.f, 0.f, 0.f, 0.f}, pc2 = {0.f, 0.f, 0.f, 0.f}, pz = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const v4f ga = *reinterpret_cast<const v4f*>(&dG[1][n][16 * jj + 4 * rb]);
-                    const v4f gb = *reinterpret_cast<const v4f*>(&dG[1][n][16 * (jj + 8) + 4 * rb]);
-                    v4f gz = ga;
-                    if (jj < 4) gz = *reinterpret_cast<const v4f*>(&dG[1][n][64 * wv + 16 * jj + 4 * rb]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        pc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[e], t_hh0[jj][e], pc, 0, 0, 0);        // -> rec0 of step t-1
-                        pc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gb[e], t_hh0[jj + 8][e], pc2, 0, 0, 0);
-                        if (jj < 4) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(gz[e], t_ih0[jj][e], pz, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pc[r] += pc2[r];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rec0[r] = pc[r];
-                if (n < 4) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dzp[t & 1][wv][4 * rb + r][n] = pz[r];
-                }
-                // the partials of step t+1 (other parity) are complete: both barriers of this step lie behind their writes
-                if (t + 1 < GT && tid < AG * 4) {
-                    const int ag = tid >> 2, k = tid & 3, q = (t + 1) & 1;
-                    dz[ag][4 * (t + 1) + k] = dzp[q][0][ag][k] + dzp[q][1][ag][k] + dzp[q][2][ag][k] + dzp[q][3][ag][k];
-                }
-            }
-            __syncthreads();
-            if (tid < AG * 4) {
-                const int ag = tid >> 2, k = tid & 3;
-                dz[ag][k] = dzp[0][0][ag][k] + dzp[0][1][ag][k] + dzp[0][2][ag][k] + dzp[0][3][ag][k];
-            }
-        }
-        __syncthreads();
-        // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
-        for (int i = tid; i < AG * 208; i += 256) {
-            const int ag = i / 208, r = i % 208, b = b0 + ag;
-            if (b >= a.B) continue;
-            const float g = dz[ag][r];
-            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
-            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
-            const float mu = zin[ag][r] + delta;
-            if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
-            if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
-            if (a.x_out) {
-                float zz = 0.f;
-                if (a.sigma != 0.f) zz = a.z ? a.z[(size_t)b * 208 + r] : normal4(a.seed, a.step_salt, (unsigned)(b * 52 + (r >> 2)))[r & 3];
-                const float xn = mu + a.sigma * zz;
-                a.x_out[(size_t)b * 208 + r] = xn;
-                if (a.x_out2) a.x_out2[(size_t)b * 208 + r] = xn;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // =============================================================================================
-// Two waves per SIMD: the same algorithm with EIGHT waves, wave w owning hidden units 8w..8w+7 of both layers.
+// MFMA formulation: 16 agents per workgroup, the recurrent products as v_mfma_f32_16x16x4_f32 tiles
 // =============================================================================================
-// With four waves (above) every SIMD holds one wave and half of a time step is dependency / LDS / barrier latency that
-// nothing covers (27k cycles per step for 13k cycles of MFMA issue).  Here every wave does half the work per step and two
-// of them share a SIMD, so one wave's cell update, exchange and barrier wait run under the other's MFMAs.
+// For a layer step the gate pre-activations of 16 agents are the GEMM [16 agents x K] x [K x 256].  Eight waves, two per SIMD;
+// wave w owns hidden units 8w..8w+7 of BOTH layers, so every wave does an eighth of a step and one wave's cell update, exchange
+// and barrier wait run under its SIMD neighbour's MFMAs (round 1's four-wave form, one wave per SIMD with 16 units each, spent
+// half of a step in latency nothing covered: 565 against 506 us).  Only h goes through LDS (the A operand of the next product)
+// -- two barriers per time step; A operands are read as float4 (4 consecutive k per lane, element e feeds MFMA e), B fragments
+// use the same k permutation.
 //   forward : a wave's gate columns are two N-tiles, P = [i of its 8 units | f of its 8 units] and Q = [g | o]; in the result
 //             layout lane (n, rb) holds column n for agents 4rb..4rb+3, so lanes n < 8 hold (i, g) and lanes n >= 8 hold
 //             (f, o) of unit n & 7.  The two half-rows trade what the other needs with one DPP row rotation by 8 each
@@ -996,7 +704,8 @@ __global__ __launch_bounds__(256) void guide_mfma_kernel(const DecoderWeights w,
 //             [W_hh0^T dG | W_ih0^T dG (4 latent channels) | 0] for layer 0, K = 256 gate columns each: lane n < 8 ends up with
 //             the recurrent gradient of unit n, lane n >= 8 with the gradient flowing down (layer 1) or with dL/dz_t, complete
 //             (layer 0; no cross-wave partial sums), and again one rotation by 8 hands each half what it needs.
-// Kept activations, the roll-out / loss scan (chain_grad) and the optimiser step are as in the four-wave kernel.
+// The activations the backward sweep needs (i, f, g, o, c of every cell and step) are kept in an L2-resident scratch, each thread
+// its own stream; the roll-out / loss scan (chain_grad) and the optimiser step are those of the 2-agent kernel.
 namespace gm8 {
 constexpr int AG = 16, HS = 68, GS = 260;
 constexpr int ACTS = GT * 2 * 5 * 2 * 512;   // floats of kept activations per workgroup: [t][layer][i f g o c][q][thread]
@@ -1058,6 +767,7 @@ __device__ unsigned long long g_guide_stamps[256 * 8];
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
 void read_guide_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guide_stamps), sizeof(unsigned long long) * 256 * 8); }
+// ... and cycle totals of the phases inside the time loops of guide_quad_kernel, printed by workgroup 0 (scripts/guide_one.py)
 #define GPHASE_DECL unsigned long long ph_[16] = {0}, phl_ = 0
 #define GPHASE_START do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(phl_)::"memory"); } while (0)
 #define GPHASE(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); ph_[k] += t_ - phl_; phl_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -1377,24 +1087,30 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
 // =============================================================================================
 // Eight agents per workgroup on the 16-block 4x4x1 fp32 MFMA: the whole chip at 2,048 agents
 // =============================================================================================
-// The 16x16x4 kernels above need 16 agents per workgroup (one M-tile), so 2,048 agents are 128 workgroups on 128 of the 256
-// CUs, and each is bound by its own MFMA issue (74 % of the time loops after round 2's clean-up): the only way to shorten a
-// guided step further is less MFMA work per CU.  v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4x4 blocks with K = 1
-// at the same fp32 rate (measured 8.4-8.8 cycles with four accumulators in turn, scripts/ubench/mfma4x4.hip: 95 % of the
-// 16x16x4 rate), so the M granularity drops to 4: 8 agents per workgroup = 256 workgroups, half the MFMA work on each CU.
-//   Transposed products: the weights are the A operand and the agents the B operand.  Forward: block = one hidden unit of this
-//   wave (16 units per wave), A row i = gate i of that unit (W[64 i + unit][k]), B column j = agent j of one quad (h[agent][k]):
-//   lane (unit, agent) receives D registers 0..3 = the i, f, g, o pre-activations of ITS cell -- all four gates of a cell in one
-//   lane with no exchange, and two MFMAs per k (the two agent quads) share the weight register.  Backward: block = (K half, which
-//   product, unit quad), A row = unit (W^T), B column = agent (the gate gradients from LDS); the two K halves are added across
-//   lane ^ 32 and a 4-way ds_bpermute hands every cell owner its unit's recurrent / downward gradient.
-//   One wave per SIMD (the K = 1 form needs one weight register per k: 196 VGPRs forward, 256 backward).
-// Kept activations, the roll-out / loss scan (chain_grad) and the optimiser step are as in the other formulations.
-namespace gq {
-constexpr int AG = 8, HS = 68, GS = 260;
-constexpr int ACTS = GT * 2 * 5 * 2 * 256;   // floats of kept activations per workgroup: [t][layer][i f g o c][agent quad][thread]
-}  // namespace gq
-
+// The 16x16x4 kernel needs 16 agents per workgroup (one M-tile): 2,048 agents are 128 workgroups on 128 of the 256 CUs, each
+// bound by its own MFMA issue.  v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4x4 blocks with K = 1 at the same fp32
+// rate (scripts/ubench/mfma4x4.hip: 8.4-9.0 cycles, the SIMD's rate whatever the number of waves), so the M granularity drops to
+// 4: 8 agents = two quads per workgroup, 256 workgroups, half the MFMA work on each CU.  What shapes the kernel (measurements in
+// scripts/ubench/{mfma_valu,lds_mfma}.hip and profiles/r02/guide_kernel_notes.md):
+//   * this short MFMA has no shadow: every other instruction of the SIMD -- VALU (+4.6 cycles a pair), transcendental (+10),
+//     LDS read, register move -- adds its issue cycles on top, from the same wave or another, so instruction COUNT is the cost;
+//   * one weight register per k (K = 1 per MFMA): 196 registers forward, 256 backward for a wave that holds all of K -- one wave
+//     per SIMD, half the weights in AGPRs behind a reload move per MFMA.  So K is split: waves wq and wq + 4 own the same 16
+//     hidden units, each takes HALF of the K dimension of every product (100 / 128 weight registers, all VGPRs, two waves per
+//     SIMD) and the cell updates of ONE agent quad (kp = wave >> 2); the partial sums for the other quad go to the partner
+//     wave through LDS;
+//   * the agents' values are the A operand (rows = the four agents of a quad) and are BROADCAST: cbsz / abid hand the rows of
+//     one 4-lane block to all 16 blocks, so one ds_read_b128 whose lanes of block b hold k-group b feeds 16 k-groups (bsweep).
+//     Every lane fetching its own copy instead moved ~100 KB per wave and step through the CU's 128 B/clk LDS port -- as long
+//     as the MFMAs take.  The weights are the B operand: lane (block = unit, column = gate) -> the sweep leaves gate q of the
+//     unit for the quad's four agents in a lane's four registers, and a 4 x 4 transpose across the unit's four lanes (DPP quad
+//     permutes) hands lane (unit, a) all four gates of agent a: the cell update runs in registers.
+// A step is two phases with one LDS barrier each -- forward: [cell updates: layer 0 of step t + 1 and layer 1 of step t] |
+// [half sweeps: layer 0 of step t + 2 and layer 1 of step t + 1]; backward: [exchanges + gate gradients: layer 1 of step s - 1
+// and layer 0 of step s] | [half products: layer 1 of step s - 1 and layer 0 of step s] -- the layer that depends on nothing
+// but itself runs one step ahead.  Backward products: block = (K half of the lane, which product, unit quad), the K quarters
+// are added across lanes l / l ^ 32 and across the wave pair, and a 4-way ds_bpermute hands every cell owner its unit's
+// recurrent / downward gradient.  Kept activations as in the 16-agent kernel; the roll-out / loss scan is chain_grad_group.
 #define CLD_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
 // The value the lane byte_lane / 4 holds.  By-value float on purpose: __builtin_bit_cast(int, v[r]) of an ext-vector ELEMENT reads
@@ -1408,8 +1124,8 @@ __device__ __forceinline__ float bperm(int byte_lane, float v) {
 //   X0 / X1 (quad 0 / quad 1): register c holds, in the lanes of block b, four consecutive k-steps of k-group PER c + b for
 //   row (lane & 3) -- ONE ds_read_b128 per register feeds PER = 16 (CB = 4) or 8 (CB = 3: one broadcast group per K half)
 //   k-groups: the MFMA's cbsz / abid fields hand block `abid`'s rows to every block of its group.  With every lane fetching its
-//   own copy of the operand (qsweep below) the four waves pulled 98 + 128 KB per step and wave through the CU's 128 B/clk LDS
-//   port -- as long as the MFMAs themselves take (profiles/r02/guide_kernel_notes.md) -- and spent an issue slot per 8 MFMAs.
+//   own copy of the operand a wave pulled 98 + 128 KB per step through the CU's 128 B/clk LDS port -- as long as the MFMAs
+//   themselves take (profiles/r02/guide_kernel_notes.md) -- and spent an issue slot per 8 MFMAs.
 //   B operand = the weights wt(g) (columns; one register per k, resident).  Accumulators [quad][k parity] in turn, so no MFMA
 //   waits for the one before it.  (abid is an immediate, hence the compile-time recursion over the k-groups.)
 template <int G, int NG, int CB, class WF>
@@ -1451,349 +1167,13 @@ __device__ __forceinline__ v4f quad_transpose(const v4f& x, bool odd1, bool odd2
     return v4f{odd2 ? r02 : y0, odd2 ? r13 : y1, odd2 ? y2 : r02, odd2 ? y3 : r13};
 }
 
-// One K sweep of the 4x4x1 products over NG groups of four k-steps: A operands wt(g) (weights, registers), B operands = the four
-// consecutive floats bptr(g, quad) points at in LDS, for the two agent quads; accumulators [quad][k parity] in turn, so no MFMA
-// waits for the one before it.  The LDS reads run two groups (16 MFMAs, ~140 cycles) ahead of their use and are pinned there
-// with scheduling barriers: with one wave per SIMD nothing else hides the read latency, and left alone the compiler issues
-// read -> wait -> 8 MFMAs -> read -> ... (measured: a guided step of 18k instead of ~10k cycles).
-template <int NG, int D = 2, class PF, class WF>
-__device__ __forceinline__ void qsweep(PF bptr, WF wt, v4f& a00, v4f& a01, v4f& a10, v4f& a11) {
-    v4f cur[D][2], nxt[D][2];        // D groups per scheduling region, fetched D groups ahead
-#pragma unroll
-    for (int j = 0; j < D; ++j)
-        if (j < NG) { cur[j][0] = *reinterpret_cast<const v4f*>(bptr(j, 0)); cur[j][1] = *reinterpret_cast<const v4f*>(bptr(j, 1)); }
-#pragma unroll
-    for (int g = 0; g < NG; g += D) {
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (g + D + j < NG) { nxt[j][0] = *reinterpret_cast<const v4f*>(bptr(g + D + j, 0)); nxt[j][1] = *reinterpret_cast<const v4f*>(bptr(g + D + j, 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < D; ++j)
-            if (g + j < NG) {
-                const v4f wv4 = wt(g + j);
-                a00 = CLD_MFMA4(wv4[0], cur[j][0][0], a00); a10 = CLD_MFMA4(wv4[0], cur[j][1][0], a10);
-                a01 = CLD_MFMA4(wv4[1], cur[j][0][1], a01); a11 = CLD_MFMA4(wv4[1], cur[j][1][1], a11);
-                a00 = CLD_MFMA4(wv4[2], cur[j][0][2], a00); a10 = CLD_MFMA4(wv4[2], cur[j][1][2], a10);
-                a01 = CLD_MFMA4(wv4[3], cur[j][0][3], a01); a11 = CLD_MFMA4(wv4[3], cur[j][1][3], a11);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < D; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
-    }
-}
-
-__global__ __launch_bounds__(256) void guide_quad_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
-    using namespace gq;
-    __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
-    __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
-    __shared__ __attribute__((aligned(16))) float zin[AG][208];
-    __shared__ __attribute__((aligned(16))) float condm[AG][256];
-    __shared__ __attribute__((aligned(16))) float hpart[4][AG][HS];     // cond2hidden: the four waves' K-quarter partials
-    __shared__ float actp[2][2][4][AG];      // [step parity][output][wave][agent]: per-wave partials of hid2act
-    __shared__ float act[2][GT][AG];         // (acceleration, yaw-rate), scaled
-    __shared__ float dact[AG][2][GT];
-    __shared__ float chs[AG][324];           // roll-out scratch of chain_grad
-    __shared__ float dz[AG][208];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ul = lane >> 2, q = lane & 3;         // MFMA lane roles: block ul; A row q; B / D column q.  Cell owner: unit ul, agents q and 4 + q
-    const int u = 16 * wv + ul;                     // this lane's hidden unit
-    const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
-
-    const int ngroups = (a.B + AG - 1) / AG;
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int b0 = grp * AG;
-        GSTAMP(0);
-        const __amdgpu_buffer_rsrc_t keep = __builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * ACTS, 0, ACTS * 4, 0x00020000);
-        const int kvo = tid * 4;
-        auto kput = [&](int slot, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), keep, kvo, slot * 1024, 0); };
-        auto kget = [&](int slot) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(keep, kvo, slot * 1024, 0)); };
-        auto agent = [&](int ag) { return (b0 + ag < a.B) ? b0 + ag : a.B - 1; };      // tail slots replay the last agent; never stored
-        for (int i = tid; i < AG * 256; i += 256) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
-        for (int i = tid; i < AG * 208; i += 256) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
-        __syncthreads();
-        {   // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49): wave wv takes the K quarter 64 wv .. 64 wv + 63 of all 64 units
-            // (block = unit quad, A row = unit, B column = agent); the four partial tiles are added below
-            const float* wr = w.w_c2h + (size_t)(4 * ul + q) * 256 + 64 * wv;
-            asm volatile("" : "+v"(wr));
-            v4f p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const v4f wa = *reinterpret_cast<const v4f*>(wr + 4 * j);
-                const v4f ca = *reinterpret_cast<const v4f*>(&condm[q][64 * wv + 4 * j]);
-                const v4f cb = *reinterpret_cast<const v4f*>(&condm[4 + q][64 * wv + 4 * j]);
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    p0 = CLD_MFMA4(wa[e], ca[e], p0); p1 = CLD_MFMA4(wa[e], cb[e], p1);
-                    p2 = CLD_MFMA4(wa[e + 1], ca[e + 1], p2); p3 = CLD_MFMA4(wa[e + 1], cb[e + 1], p3);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {            // D lane (unit quad ul, agent q): register r = unit 4 ul + r
-                hpart[wv][q][4 * ul + r] = p0[r] + p2[r];
-                hpart[wv][4 + q][4 * ul + r] = p1[r] + p3[r];
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < AG * 64; i += 256) {
-            const int ag = i >> 6, uu = i & 63;
-            const float v = w.b_c2h[uu] + hpart[0][ag][uu] + hpart[1][ag][uu] + hpart[2][ag][uu] + hpart[3][ag][uu];
-            hs[0][0][ag][uu] = v;
-            hs[1][0][ag][uu] = v;
-        }
-        GPHASE_DECL;
-        float c0[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f};
-        __syncthreads();
-        GSTAMP(1);
-        // ---------------- forward ----------------
-        {
-            // weights as B operands: lane (block = unit ul, column = gate q) holds row 64 q + u of every matrix, one register per k; a
-            // sweep leaves gate q of unit u for the four agents of a quad in this lane's four registers, and a 4 x 4 transpose across
-            // the quad's lanes (the four gates of the unit) hands lane (ul, a) all four gates of agent a.  The pointers are opaque
-            // inside the group loop (see guide_mfma8_kernel)
-            const float *p_hh0 = w.w_hh0 + (size_t)(64 * q + u) * 64, *p_ih1 = w.w_ih1 + (size_t)(64 * q + u) * 64,
-                        *p_hh1 = w.w_hh1 + (size_t)(64 * q + u) * 64, *p_ih0 = w.w_ih0 + (size_t)(64 * q + u) * 4, *p_b0 = w.b0 + u, *p_b1 = w.b1 + u;
-            asm volatile("" : "+v"(p_hh0), "+v"(p_ih1), "+v"(p_hh1), "+v"(p_ih0), "+v"(p_b0), "+v"(p_b1));
-            v4f f_ih0 = *reinterpret_cast<const v4f*>(p_ih0), f_hh0[16], f_ih1[16], f_hh1[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                f_hh0[j] = *reinterpret_cast<const v4f*>(p_hh0 + 4 * j);
-                f_ih1[j] = *reinterpret_cast<const v4f*>(p_ih1 + 4 * j);
-                f_hh1[j] = *reinterpret_cast<const v4f*>(p_hh1 + 4 * j);
-            }
-            // biases: this lane's column is gate q of unit u; D register r = agent r of the quad
-            const float bq0 = p_b0[64 * q], bq1 = p_b1[64 * q];
-            const v4f bias0 = {bq0, bq0, bq0, bq0}, bias1 = {bq1, bq1, bq1, bq1};
-            const v4f zero = {0.f, 0.f, 0.f, 0.f};
-            GSTAMP(2);
-            GPHASE_START;
-            for (int t = 0; t < GT; ++t) {
-                const int pr = t & 1;
-                if (t > 0 && tid < 2 * AG) {      // actions of step t-1: the four per-wave partials (written before the last barrier)
-                    const int o = tid >> 3, ag = tid & 7;
-                    act[o][t - 1][ag] = (o ? bh2b : bh2a) + actp[pr ^ 1][o][0][ag] + actp[pr ^ 1][o][1][ag] + actp[pr ^ 1][o][2][ag] + actp[pr ^ 1][o][3][ag];
-                }
-                // ---- layer 0: pre = b + W_ih0 x_t + W_hh0 h0_{t-1}; accumulators [agent quad][k parity] ----
-                v4f a00 = bias0, a01 = zero, a10 = bias0, a11 = zero;
-                {
-                    // lane (block ul, row q): agent 4 aq + q, k-group ul of h0_{t-1}; x_t: the same four channels in every block
-                    const v4f Xh[2] = {*reinterpret_cast<const v4f*>(&hs[0][pr][q][4 * ul]), *reinterpret_cast<const v4f*>(&hs[0][pr][4 + q][4 * ul])};
-                    const v4f Xx[2] = {*reinterpret_cast<const v4f*>(&zin[q][4 * t]), *reinterpret_cast<const v4f*>(&zin[4 + q][4 * t])};
-                    bsweep<0, 1, 4>(&Xx[0], &Xx[1], [&](int) { return f_ih0; }, a00, a01, a10, a11);
-                    bsweep<0, 16, 4>(&Xh[0], &Xh[1], [&](int g) { return f_hh0[g]; }, a00, a01, a10, a11);
-                }
-                GPHASE(0);
-                int ks = (t * 2 + 0) * 10;          // slot of (step t, layer 0, gate 0, quad 0); a slot = one float per thread
-#pragma unroll
-                for (int aq = 0; aq < 2; ++aq) {
-                    const v4f P = quad_transpose(aq ? a10 + a11 : a00 + a01, q & 1, q & 2);      // gate q x four agents -> agent q x four gates
-                    const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
-                    const float c = f_ * c0[aq] + i_ * g_;
-                    c0[aq] = c;
-                    hs[0][pr ^ 1][4 * aq + q][u] = o_ * ftanh(c);
-                    kput(ks + 0 + aq, i_); kput(ks + 2 + aq, f_); kput(ks + 4 + aq, g_); kput(ks + 6 + aq, o_); kput(ks + 8 + aq, c);
-                }
-                GPHASE(1);
-                lds_barrier();
-                GPHASE(2);
-                // ---- layer 1: pre = b + W_ih1 h0_t + W_hh1 h1_{t-1} ----
-                a00 = bias1; a01 = zero; a10 = bias1; a11 = zero;
-                {
-                    const v4f Xa[2] = {*reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][q][4 * ul]), *reinterpret_cast<const v4f*>(&hs[0][pr ^ 1][4 + q][4 * ul])};
-                    const v4f Xb[2] = {*reinterpret_cast<const v4f*>(&hs[1][pr][q][4 * ul]), *reinterpret_cast<const v4f*>(&hs[1][pr][4 + q][4 * ul])};
-                    bsweep<0, 16, 4>(&Xa[0], &Xa[1], [&](int g) { return f_ih1[g]; }, a00, a01, a10, a11);
-                    bsweep<0, 16, 4>(&Xb[0], &Xb[1], [&](int g) { return f_hh1[g]; }, a00, a01, a10, a11);
-                }
-                GPHASE(3);
-                ks += 10;
-                float ap[2], aq_[2];
-#pragma unroll
-                for (int aq = 0; aq < 2; ++aq) {
-                    const v4f P = quad_transpose(aq ? a10 + a11 : a00 + a01, q & 1, q & 2);      // gate q x four agents -> agent q x four gates
-                    const float i_ = fsig(P[0]), f_ = fsig(P[1]), g_ = ftanh(P[2]), o_ = fsig(P[3]);
-                    const float c = f_ * c1[aq] + i_ * g_;
-                    c1[aq] = c;
-                    const float hn = o_ * ftanh(c);
-                    hs[1][pr ^ 1][4 * aq + q][u] = hn;
-                    kput(ks + 0 + aq, i_); kput(ks + 2 + aq, f_); kput(ks + 4 + aq, g_); kput(ks + 6 + aq, o_); kput(ks + 8 + aq, c);
-                    ap[aq] = hn * wa0;                      // hid2act: partials over this wave's 16 units
-                    aq_[aq] = hn * wa1;
-                }
-#pragma unroll
-                for (int aq = 0; aq < 2; ++aq) { ap[aq] = sum_over_units(ap[aq]); aq_[aq] = sum_over_units(aq_[aq]); }
-                if (ul == 0) {
-#pragma unroll
-                    for (int aq = 0; aq < 2; ++aq) { actp[pr][0][wv][4 * aq + q] = ap[aq]; actp[pr][1][wv][4 * aq + q] = aq_[aq]; }
-                }
-                GPHASE(4);
-                lds_barrier();
-                GPHASE(5);
-            }
-        }
-        GSTAMP(3);
-        // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
-        if (tid < 2 * AG) {
-            const int o = tid >> 3, ag = tid & 7, pl = (GT - 1) & 1;
-            act[o][GT - 1][ag] = (o ? bh2b : bh2a) + actp[pl][o][0][ag] + actp[pl][o][1][ag] + actp[pl][o][2][ag] + actp[pl][o][3][ag];
-        }
-        __syncthreads();
-        if (tid < AG)
-            chain_grad(d, a, agent(tid), &act[0][0][tid], &act[1][0][tid], AG, &dact[tid][0][0], &dact[tid][1][0], &chs[tid][0]);
-        __syncthreads();
-        GSTAMP(4);
-        // ---------------- backward through time ----------------
-        {
-            // B operands of the products, pre-packed at cld_finalize (DecoderWeights::gqfrag): lane (block = (K half kh, product m,
-            // unit quad ub), column j) holds W_m[gate column kk + 128 kh][unit 16 wv + 4 ub + j] for kk = 0..127
-            //   layer 1: m = 0 -> W_hh1 (recurrent gradient), m = 1 -> W_ih1 (gradient flowing down to layer 0)
-            //   layer 0: m = 0 -> W_hh0, m = 1 / ub = 0 -> W_ih0[.][latent channel i] (dL/dz_t), else 0
-            const v4f* gf = reinterpret_cast<const v4f*>(w.gqfrag) + (size_t)wv * (2 * 32 * 64) + lane;
-            asm volatile("" : "+v"(gf));
-            v4f t1[32], t0[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) { t1[j] = gf[j * 64]; t0[j] = gf[(32 + j) * 64]; }
-            const int kh = lane >> 5;
-            // owner lane (unit ul, agent q) <- result lane (kh 0, product m, unit quad ul >> 2, column ul & 3) = lane 16 m + ul, register q
-            const int src_rec = ul * 4, src_dwn = src_rec + 64, rsel = q;
-            auto pick = [&](const v4f& v, int byte_lane) {
-                const float x0 = bperm(byte_lane, v[0]), x1 = bperm(byte_lane, v[1]), x2 = bperm(byte_lane, v[2]), x3 = bperm(byte_lane, v[3]);
-                return rsel == 0 ? x0 : (rsel == 1 ? x1 : (rsel == 2 ? x2 : x3));
-            };
-            // [8 agents x 256 gate columns] x [256 x this wave's 32 columns]: A operand = the agents' rows of the gate-gradient tile,
-            // one K half per broadcast group of 8 blocks: lane (kh, block b of the half, row q) reads the four columns of k-group
-            // 8 c + b of its half -> R0 / R1 (agent quads), K halves added
-            auto tprodq = [&](const float (*gsrc)[GS], const v4f (&tw)[32], v4f& R0, v4f& R1) {
-                v4f p00 = {0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
-                const float* g0 = &gsrc[q][128 * kh + 4 * (ul & 7)];
-                const float* g1 = &gsrc[4 + q][128 * kh + 4 * (ul & 7)];
-                v4f X0[4], X1[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { X0[c] = *reinterpret_cast<const v4f*>(g0 + 32 * c); X1[c] = *reinterpret_cast<const v4f*>(g1 + 32 * c); }
-                bsweep<0, 32, 3>(X0, X1, [&](int g) { return tw[g]; }, p00, p01, p10, p11);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s0 = p00[r] + p01[r], s1 = p10[r] + p11[r];
-                    R0[r] = s0 + __shfl_xor(s0, 32);
-                    R1[r] = s1 + __shfl_xor(s1, 32);
-                }
-            };
-            float rec1[2] = {0.f, 0.f}, rec0[2] = {0.f, 0.f};
-            float dc1n[2] = {0.f, 0.f}, dc0n[2] = {0.f, 0.f};
-            float kv1[6][2], kv0[6][2];
-            auto fetch = [&](float (&kv)[6][2], int t, int layer) {
-                const int ks = (t * 2 + layer) * 10;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-#pragma unroll
-                    for (int aq = 0; aq < 2; ++aq) kv[k][aq] = kget(ks + 2 * k + aq);
-#pragma unroll
-                for (int aq = 0; aq < 2; ++aq) kv[5][aq] = t > 0 ? kget(ks - 20 + 8 + aq) : 0.f;      // the cell state of step t-1, same layer
-            };
-            fetch(kv1, GT - 1, 1);
-            GSTAMP(5);
-            GPHASE_START;
-            for (int t = GT - 1; t >= 0; --t) {
-                // ---- layer 1 gate gradients -> LDS ----
-#pragma unroll
-                for (int aq = 0; aq < 2; ++aq) {
-                    const float i_ = kv1[0][aq], f_ = kv1[1][aq], g_ = kv1[2][aq], o_ = kv1[3][aq], c = kv1[4][aq], cp = kv1[5][aq];
-                    const float tc = ftanh(c);
-                    const float dh = wa0 * dact[4 * aq + q][0][t] + wa1 * dact[4 * aq + q][1][t] + rec1[aq];
-                    const float dc = dh * o_ * (1.f - tc * tc) + dc1n[aq];
-                    float* row = &dG[0][4 * aq + q][u];
-                    row[0] = dc * g_ * i_ * (1.f - i_);
-                    row[64] = dc * cp * f_ * (1.f - f_);
-                    row[128] = dc * i_ * (1.f - g_ * g_);
-                    row[192] = dh * tc * o_ * (1.f - o_);
-                    dc1n[aq] = dc * f_;
-                }
-                GPHASE(6);
-                lds_barrier();
-                GPHASE(7);
-                fetch(kv0, t, 0);
-                v4f R0, R1;
-                tprodq(dG[0], t1, R0, R1);
-                GPHASE(8);
-                float down[2];
-                rec1[0] = pick(R0, src_rec); rec1[1] = pick(R1, src_rec);
-                down[0] = pick(R0, src_dwn); down[1] = pick(R1, src_dwn);
-                GPHASE(9);
-                // ---- layer 0 gate gradients -> LDS ----
-#pragma unroll
-                for (int aq = 0; aq < 2; ++aq) {
-                    const float i_ = kv0[0][aq], f_ = kv0[1][aq], g_ = kv0[2][aq], o_ = kv0[3][aq], c = kv0[4][aq], cp = kv0[5][aq];
-                    const float tc = ftanh(c);
-                    const float dh = down[aq] + rec0[aq];
-                    const float dc = dh * o_ * (1.f - tc * tc) + dc0n[aq];
-                    float* row = &dG[1][4 * aq + q][u];
-                    row[0] = dc * g_ * i_ * (1.f - i_);
-                    row[64] = dc * cp * f_ * (1.f - f_);
-                    row[128] = dc * i_ * (1.f - g_ * g_);
-                    row[192] = dh * tc * o_ * (1.f - o_);
-                    dc0n[aq] = dc * f_;
-                }
-                GPHASE(10);
-                lds_barrier();
-                GPHASE(11);
-                if (t > 0) fetch(kv1, t - 1, 1);
-                tprodq(dG[1], t0, R0, R1);
-                GPHASE(12);
-                rec0[0] = pick(R0, src_rec); rec0[1] = pick(R1, src_rec);
-                // dL/dz_t, complete: result lanes (kh 0, product 1, unit quad 0, column = latent channel q) = lanes 16..19, register r = agent r
-                if (wv == 0 && lane >= 16 && lane < 20) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { dz[r][4 * t + q] = R0[r]; dz[4 + r][4 * t + q] = R1[r]; }
-                }
-                GPHASE(13);
-            }
-        }
-            GPHASE_PRINT(14);
-        __syncthreads();
-        GSTAMP(6);
-        // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
-        for (int i = tid; i < AG * 208; i += 256) {
-            const int ag = i / 208, r = i % 208, b = b0 + ag;
-            if (b >= a.B) continue;
-            const float g = dz[ag][r];
-            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
-            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
-            const float mu = zin[ag][r] + delta;
-            if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
-            if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
-            if (a.x_out) {
-                float zz = 0.f;
-                if (a.sigma != 0.f) zz = a.z ? a.z[(size_t)b * 208 + r] : normal4(a.seed, a.step_salt, (unsigned)(b * 52 + (r >> 2)))[r & 3];
-                const float xn = mu + a.sigma * zz;
-                a.x_out[(size_t)b * 208 + r] = xn;
-                if (a.x_out2) a.x_out2[(size_t)b * 208 + r] = xn;
-            }
-        }
-        GSTAMP(7);
-        __syncthreads();
-    }
-}
-
-// =============================================================================================
-// The same 8-agent formulation with the K dimension of every product split between two waves
-// =============================================================================================
-// guide_quad_kernel is bound by ONE wave's instruction issue per SIMD: a 4x4x1 MFMA occupies the wave for ~8 cycles and every
-// other instruction adds its own issue cycles on top (measured, scripts/ubench/mfma_valu.hip: +4.6 cycles per plain VALU pair,
-// +10 per transcendental, whatever the number of waves -- this MFMA has no shadow to hide VALU work in), and its backward
-// weights (256 registers) live half in AGPRs, which costs a reload move for every other MFMA.  Here eight waves share the work:
-// waves wq and wq + 4 own the same 16 hidden units but each takes HALF of the K dimension of every product (so half the weight
-// registers: 100 forward, 128 backward, all in VGPRs at two waves per SIMD) and the cell updates of ONE agent quad (kp = wave
-// >> 2).  The partial sums of the quad a wave does not own go to its partner through LDS.  A step is two phases with one
-// barrier each -- forward: [cell updates: layer 0 of step t + 1 and layer 1 of step t] | [half sweeps: layer 0 of step t + 2
-// and layer 1 of step t + 1]; backward: [exchanges + gate gradients: layer 1 of step s - 1 and layer 0 of step s] | [half
-// products: layer 1 of step s - 1 and layer 0 of step s] -- the layer that depends on nothing but itself runs one step ahead.
-namespace gq2 {
+namespace gq {
 constexpr int AG = 8, HS = 68, GS = 260;
 constexpr int ACTS = GT * 2 * 5 * 512;       // floats of kept activations per workgroup: [t][layer][i f g o c][thread]
-}  // namespace gq2
+}  // namespace gq
 
-__global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
-    using namespace gq2;
+__global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
+    using namespace gq;
     __shared__ __attribute__((aligned(16))) float hs[2][2][AG][HS];     // [layer][parity][agent][unit]
     __shared__ __attribute__((aligned(16))) float dG[2][AG][GS];        // gate gradients of layer 1 / layer 0
     __shared__ __attribute__((aligned(16))) float zin[AG][208];
@@ -1817,6 +1197,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
     const int ngroups = (a.B + AG - 1) / AG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int b0 = grp * AG;
+        GSTAMP(0);
         const __amdgpu_buffer_rsrc_t keep = __builtin_amdgcn_make_buffer_rsrc(a.scratch + (size_t)blockIdx.x * ACTS, 0, ACTS * 4, 0x00020000);
         const int kvo = tid * 4;
         auto kput = [&](int slot, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), keep, kvo, slot * 2048, 0); };
@@ -1856,6 +1237,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
         float c0 = 0.f, c1 = 0.f;
         GPHASE_DECL;
         __syncthreads();
+        GSTAMP(1);
         // ---------------- forward ----------------
         {
             // weights as B operands (columns = the four gates of this lane's unit): this wave's K half, one register per k
@@ -1919,6 +1301,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
                 actp[t][0][wq][ao] = sum_over_units(hn * wa0);      // hid2act: partials over this wave's 16 units
                 actp[t][1][wq][ao] = sum_over_units(hn * wa1);      // (the 16 lanes of a column hold the same sum)
             };
+            GSTAMP(2);
             half0(0);
             lds_barrier();
             cell0(0);
@@ -1941,6 +1324,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
                 GPHASE(5);
             }
         }
+        GSTAMP(3);
         // ---------------- speed chain + loss gradient (diffuser_helpers.py:573-600; guidance_loss.py:229-254) ----------------
         for (int i = tid; i < 2 * GT * AG; i += 512) {
             const int o = i / (GT * AG), t = (i / AG) % GT, ag = i % AG;
@@ -1948,9 +1332,12 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
         }
         __syncthreads();
         chain_grad_group<AG, 512>(d, a, agent, &act[0][0][0], &act[1][0][0], AG, &dact[0][0][0], &chs[0][0]);
+        GSTAMP(4);
         // ---------------- backward through time ----------------
         {
-            // B operands of the products (DecoderWeights::gqfrag, see guide_quad_kernel): block = (K half kh, product m, unit quad ub);
+            // B operands of the products, pre-packed at cld_finalize (DecoderWeights::gqfrag): lane (block = (K half kh, product m, unit
+            // quad ub), column j) holds W_m[gate column kk + 128 kh][unit 16 wq + 4 ub + j] for kk = 0..127 (layer 1: m = 0 -> W_hh1,
+            // m = 1 -> W_ih1; layer 0: m = 0 -> W_hh0, m = 1 / ub = 0 -> W_ih0[.][latent channel j], else 0);
             // of the 32 k-groups of a lane this wave takes groups 16 kp .. 16 kp + 15, i.e. gate columns 128 kh + 64 kp + 4 g + e --
             // the four K quarters are added across lanes l / l ^ 32 and across the two waves
             const v4f* gf = reinterpret_cast<const v4f*>(w.gqfrag) + (size_t)wq * (2 * 32 * 64) + (size_t)kp * (16 * 64) + lane;
@@ -2016,6 +1403,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
                     for (int r = 0; r < 4; ++r) dz[4 * kp + r][4 * s + q] = S[r];
                 }
             };
+            GSTAMP(5);
             // prologue: layer 1 at the last step
             fetch(kv1, GT - 1, 1);
             fetch(kv0, GT - 1, 0);
@@ -2050,6 +1438,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
             xchg0(0);
             GPHASE_PRINT(14);
         }
+        GSTAMP(6);
         __syncthreads();
         // ---------------- one optimiser step on the mean (clipped if asked); then the ancestral noise ----------------
         for (int i = tid; i < AG * 208; i += 512) {
@@ -2074,7 +1463,7 @@ __global__ __launch_bounds__(512) void guide_quad2_kernel(const DecoderWeights w
 }
 
 static int guide_mfma_grid(int B) {
-    const int groups = (B + gm::AG - 1) / gm::AG;
+    const int groups = (B + gm8::AG - 1) / gm8::AG;
     return groups < 256 ? groups : 256;
 }
 static int guide_quad_grid(int B) {
@@ -2082,30 +1471,26 @@ static int guide_quad_grid(int B) {
     return groups < 256 ? groups : 256;
 }
 // Which formulation by batch size.  The MFMA kernels put one workgroup on a CU and each workgroup is bound by its own instruction
-// issue, so what counts is the number of ROUNDS of workgroups over the 256 CUs: the 8-agent kernel (a round costs ~0.67 of a
-// 16-agent round: 340 vs 506 us) wins whenever it needs fewer than 1.5 x the rounds of the 16-agent kernel -- up to 2,048 agents
+// issue, so what counts is the number of ROUNDS of workgroups over the 256 CUs: the 8-agent kernel (a round costs ~0.63 of a
+// 16-agent round: 318 vs 506 us) wins whenever it needs fewer than 1.5 x the rounds of the 16-agent kernel -- up to 2,048 agents
 // (one round each), not from 2,049 to 4,096 (two rounds against one), ...; a single round of the 2-agent VALU kernel
-// (up to 512 agents) takes as long as a round of the 8-agent kernel (340 vs 326 us), so it only keeps the smallest batches.
+// (up to 512 agents) takes as long as a round of the 8-agent kernel (340 vs 318 us), so it only keeps the smallest batches.
 // Tests force each form through cld_debug_force_kernel.
 static int guide_form(int B, int form) {
     if (form != FORM_AUTO) return form;
     if (B < 64) return FORM_VALU;
     const int r8 = (B + 8 * 256 - 1) / (8 * 256), r16 = (B + 16 * 256 - 1) / (16 * 256);
-    return 2 * r8 < 3 * r16 ? FORM_MFMA_QUAD2 : FORM_MFMA;
+    return 2 * r8 < 3 * r16 ? FORM_MFMA_QUAD : FORM_MFMA;
 }
 size_t guide_scratch_floats(int B) {
     const size_t valu = (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS);
-    static_assert(gm::ACTS == gm8::ACTS, "both 16-agent MFMA formulations keep the same number of activations per workgroup");
-    static_assert(gq::ACTS == gq2::ACTS, "both 8-agent formulations keep the same number of activations per workgroup");
-    const size_t mfma = (size_t)guide_mfma_grid(B) * gm::ACTS, quad = (size_t)guide_quad_grid(B) * gq::ACTS;
+    const size_t mfma = (size_t)guide_mfma_grid(B) * gm8::ACTS, quad = (size_t)guide_quad_grid(B) * gq::ACTS;
     return valu > mfma ? (valu > quad ? valu : quad) : (mfma > quad ? mfma : quad);
 }
 
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
     switch (guide_form(a.B, form)) {
-        case FORM_MFMA_QUAD: hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(256), 0, s, w, d, a); break;
-        case FORM_MFMA_QUAD2: hipLaunchKernelGGL(guide_quad2_kernel, dim3(guide_quad_grid(a.B)), dim3(512), 0, s, w, d, a); break;
-        case FORM_MFMA_4WAVE: hipLaunchKernelGGL(guide_mfma_kernel, dim3(guide_mfma_grid(a.B)), dim3(256), 0, s, w, d, a); break;
+        case FORM_MFMA_QUAD: hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(512), 0, s, w, d, a); break;
         case FORM_MFMA: hipLaunchKernelGGL(guide_mfma8_kernel, dim3(guide_mfma_grid(a.B)), dim3(512), 0, s, w, d, a); break;
         default: hipLaunchKernelGGL(guide_kernel, dim3(guide_grid(a.B)), dim3(256), 0, s, w, d, a);
     }

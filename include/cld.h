@@ -350,10 +350,8 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_KERNEL_ENCODE 2   /* cld_traj2z */
 #define CLD_FORM_AUTO 0       /* by batch size (default) */
 #define CLD_FORM_VALU 1       /* one or two agents per workgroup, gate rows in registers */
-#define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 MFMA tiles */
-#define CLD_FORM_MFMA_4WAVE 3 /* guide only: the 16-agent form with one wave per SIMD (kept for A/B) */
-#define CLD_FORM_MFMA_QUAD 4  /* guide only: 8 agents per workgroup on the 16-block 4x4x1 fp32 MFMA, one wave per SIMD */
-#define CLD_FORM_MFMA_QUAD2 5 /* guide only: the same with the K dimension split between two waves per SIMD */
+#define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 16x16x4 MFMA tiles */
+#define CLD_FORM_MFMA_QUAD 3  /* guide only: 8 agents per workgroup on the 16-block 4x4x1 fp32 MFMA (the form 2,048 agents run in) */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);
 
 /* CLD_PRECISION_* the handle runs with. */

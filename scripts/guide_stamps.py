@@ -6,7 +6,7 @@ import numpy as np, torch
 from cld_amd import synth
 from cld_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-FORM = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # 4 = 8 agents per workgroup (4x4x1 MFMA), 2 = 16 agents, two waves per SIMD, 3 = one
+FORM = int(sys.argv[2]) if len(sys.argv) > 2 else 3      # 3 = 8 agents per workgroup (4x4x1 MFMA), 2 = 16 agents (16x16x4 MFMA)
 e = Engine(10, "cuda:0"); e.load_state_dict(synth.make_unet_weights(0)); e.load_state_dict(synth.make_decoder_weights(0)); e.finalize()
 e._check(e.lib.cld_debug_force_kernel(e._h, 0, FORM), "force")
 g = torch.Generator(device="cuda"); g.manual_seed(B)
@@ -19,7 +19,7 @@ for _ in range(20):
 torch.cuda.synchronize()
 out = np.zeros(2048, np.uint64)
 e.lib.cld_debug_guide_stamps(out.ctypes.data)
-s = out.reshape(256, 8).astype(np.int64)[: min(256, (B + 7) // 8 if FORM == 4 else (B + 15) // 16)]
+s = out.reshape(256, 8).astype(np.int64)[: min(256, (B + 7) // 8 if FORM == 3 else (B + 15) // 16)]
 d = np.diff(s[:, :7], axis=1)
 names = ["load cond / mean + cond2hidden", "forward weights", "forward 52 steps", "actions + roll-out scan (chain_grad)", "backward weights + first fetch", "backward 52 steps"]
 tot = (s[:, 6] - s[:, 0]).mean()

@@ -387,9 +387,9 @@ def test_get_action_from_raw_observation(eng_ctx):
 
 
 def test_guidance_mfma_kernel_vs_oracle_and_valu(eng_jitter):
-    """The MFMA formulations of the guidance kernel (16 agents per workgroup on 16x16x4 tiles, two and one wave per SIMD; 8
-    agents per workgroup on the 4x4x1 blocks): gradient against the oracle's autograd at B = 523 (ragged last tile in every
-    form), and against the 2-agent VALU kernel on the same inputs."""
+    """The MFMA formulations of the guidance kernel (16 agents per workgroup on 16x16x4 tiles; 8 agents per workgroup on the
+    4x4x1 blocks): gradient against the oracle's autograd at B = 523 (ragged last tile in both), and against the 2-agent VALU
+    kernel on the same inputs."""
     import os
     from oracle import cld_oracle as O
     B = 523
@@ -399,7 +399,7 @@ def test_guidance_mfma_kernel_vs_oracle_and_valu(eng_jitter):
     tgt = torch.from_numpy(synth.uniform(21, "guide_target_speed", (B, 52), 0.0, 12.0))
     gd = {"curr_states": cs, "target_speed": tgt, "lr": 2.0, "perturb_th": None, "optimizer": "sgd"}
     outs = {}
-    for k in ("mfma", "mfma4", "quad", "quad2", "valu"):
+    for k in ("mfma", "quad", "valu"):
         eng_jitter.force_kernel("guide", k)
         try:
             outs[k] = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
@@ -411,7 +411,7 @@ def test_guidance_mfma_kernel_vs_oracle_and_valu(eng_jitter):
     gmax = gref.abs().max().item()
     for k in outs:
         assert (outs[k][1].cpu() - gref).abs().max().item() <= 2e-5 * gmax, k
-    for k in ("mfma", "mfma4", "quad", "quad2"):
+    for k in ("mfma", "quad"):
         assert (outs[k][0] - outs["valu"][0]).abs().max().item() <= 2.0 * 4e-5 * gmax + 2.5e-7, k
 
 
@@ -447,7 +447,7 @@ def test_vae_forward_reconstruction_path():
     assert (out["output"].cpu() - ref[..., :2]).abs().max().item() <= 2e-4 * max(1.0, ref[..., :2].abs().max().item())
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad", "quad2"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
     """Target-speed + speed-limit + acceleration-limit guidance in one step against the reference's own perturb() (golden
     'guidance', combo_sgd), through both formulations of the guidance kernel."""
@@ -474,7 +474,7 @@ def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
     assert bool(torch.isfinite(only).all())
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad", "quad2"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_guidance_waypoint_golden(golden, eng_jitter, kernel):
     """Waypoint guidance (TargetPosAtTimeLoss): the gradient runs through positions, yaw and the speed-dependent yaw-rate
     bound of the unicycle roll-out, then through both decoder output channels.  Against the reference's perturb() (golden
@@ -503,7 +503,7 @@ def test_guidance_waypoint_golden(golden, eng_jitter, kernel):
     assert np.abs(mg.cpu().numpy() - g["guided_waypoint_sgd"]).max() <= max(5e-5 * step, 2.5e-7)
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad", "quad2"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_guidance_waypoint_yaw_bound_path(kernel):
     """The yaw-rate clip of the roll-out (bound = max(min(0.5|v|, 2pi/|v|), 0.1)) routes the waypoint gradient into the speed
     when it is active.  The reference statistics never reach it with random weights, so this case widens the yaw-rate scale
@@ -545,7 +545,7 @@ def test_guidance_waypoint_yaw_bound_path(kernel):
     assert (grad.cpu() - gref).abs().max().item() <= 1e-4 * gref.abs().max().item()
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad", "quad2"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_guidance_targetpos_softmin_golden(golden, eng_jitter, kernel):
     """TargetPosLoss (softmin over the steps >= m, encoded as target_time = -(m + 1)) against the reference's perturb()."""
     import os
@@ -622,7 +622,7 @@ def test_non_cond_feat_for_classifier_free_guidance(eng_ctx):
     assert (aux["non_cond_feat"] - aux["cond_feat"]).abs().max().item() > 1e-2
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad", "quad2"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_decode_vjp_vs_autograd(kernel):
     """Engine.decode_vjp = J^T g for J = d decode / d z (decoder + descale + unicycle roll-out, all six trajectory channels,
     yaw-rate clip active on part of the steps): against torch autograd through the oracle's decode for a random g."""
