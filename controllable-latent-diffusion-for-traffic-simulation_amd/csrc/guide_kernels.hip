@@ -1155,6 +1155,13 @@ __device__ __forceinline__ float sum_over_units(float x) {
     return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);   // lower + upper half
 }
 
+// x + (the value lane ^ 32 holds), in both lanes: one v_permlane32_swap and one add, no LDS crossbar
+__device__ __forceinline__ float add_other_half(float x) {
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+    const unsigned a32 = r32[0], b32 = r32[1];
+    return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);
+}
+
 // 4 x 4 transpose across the four lanes of a quad: out[g] = register (lane & 3) of the quad's lane g.  Two butterfly stages
 // (lane bit 0 with register bit 0, then bit 1 with bit 1), each one select for what to send, one DPP quad permute, two selects.
 __device__ __forceinline__ float quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false)); }
@@ -1168,7 +1175,9 @@ __device__ __forceinline__ v4f quad_transpose(const v4f& x, bool odd1, bool odd2
 }
 
 namespace gq {
-constexpr int AG = 8, HS = 68, GS = 260;
+// row strides = 16 (mod 64 banks): the four agent rows a wave touches with one instruction -- 16 consecutive units each in the
+// scalar writes, four 16-byte k-groups each in the first 16 lanes of a b128 read -- land on disjoint banks
+constexpr int AG = 8, HS = 80, GS = 272;
 constexpr int ACTS = GT * 2 * 5 * 512;       // floats of kept activations per workgroup: [t][layer][i f g o c][thread]
 }  // namespace gq
 
@@ -1347,7 +1356,7 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
             for (int j = 0; j < 16; ++j) { t1[j] = gf[j * 64]; t0[j] = gf[(32 + j) * 64]; }
             const int kh = lane >> 5;
             // owner lane (unit ul, agent q) <- result lane (kh 0, product m, unit quad ul >> 2, column ul & 3) = lane 16 m + ul, register q
-            const int src_rec = ul * 4, src_dwn = src_rec + 64, rsel = q, xor32 = (lane ^ 32) * 4;
+            const int src_rec = ul * 4, src_dwn = src_rec + 64, rsel = q;
             auto pick = [&](const v4f& v, int byte_lane) {
                 const float x0 = bperm(byte_lane, v[0]), x1 = bperm(byte_lane, v[1]), x2 = bperm(byte_lane, v[2]), x3 = bperm(byte_lane, v[3]);
                 return rsel == 0 ? x0 : (rsel == 1 ? x1 : (rsel == 2 ? x2 : x3));
@@ -1365,7 +1374,7 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
                 bsweep<0, 16, 3>(X0, X1, [&](int g) { return tw[g]; }, p00, p01, p10, p11);
                 v4f S0 = p00 + p01, S1 = p10 + p11;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { S0[r] += bperm(xor32, S0[r]); S1[r] += bperm(xor32, S1[r]); }
+                for (int r = 0; r < 4; ++r) { S0[r] = add_other_half(S0[r]); S1[r] = add_other_half(S1[r]); }
                 *reinterpret_cast<v4f*>(&xch[lay][wv8][lane][0]) = kp ? S0 : S1;
                 keepS = kp ? S1 : S0;
             };

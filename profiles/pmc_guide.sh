@@ -1,7 +1,8 @@
 #!/bin/bash
-# SQ counter passes for the guidance kernel (one formulation, 2,048 agents):  bash profiles/pmc_guide.sh <tag> <form> [lib]
+# SQ counter passes for the guidance kernel (one formulation -- 3 = 8-agent 4x4x1, 2 = 16-agent 16x16x4 -- at 2,048 agents):
+#   bash profiles/pmc_guide.sh <tag> <form> [lib]   -> gpurun_out/<tag>/p1..p4 and a per-launch summary on stdout
 set -u
-TAG=${1:-pg}; FORM=${2:-4}; R=$GRAFT_REPO_ROOT
+TAG=${1:-pg}; FORM=${2:-3}; R=$GRAFT_REPO_ROOT
 [ -n "${3:-}" ] && export CLD_LIB_PATH=$R/controllable-latent-diffusion-for-traffic-simulation_amd/$3
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
