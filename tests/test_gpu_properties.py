@@ -336,6 +336,40 @@ def test_full_size_chain_vs_oracle(eng, oracle_w):
     assert float((lp.cpu() - ref["log_prob_final"]).abs().max()) <= 1e-4
 
 
+def test_configs2_guided_cfg_chain_at_full_size_vs_oracle(precision):
+    """BASELINE configs[2] at its full launch sizes -- 32 x 64 = 2,048 agents, CFG w = 2 (both passes one 4,096-row launch set),
+    guidance gradient on every step t > 0 (2,048 agents: the 8-agents-per-workgroup kernel on all 256 CUs, the form the bench
+    runs) -- on a 6-step schedule, directly against the oracle's autograd restatement with the same noise (the GPU box's host
+    cores finish it in a few seconds).  Same bar as the small guided chains: Adam's sign-like step can flip where |g| ~ 1e-8
+    between two fp32 implementations, so a handful of elements may move by one step of lr; all others within 1e-3 of max|x0|.
+    Zero loss weight must still reproduce the unguided CFG chain bit for bit at this size."""
+    from oracle import cld_oracle as O
+    from cld_amd.engine import Engine
+    B, n = 2048, 6
+    e = Engine(n, "cuda:0", precision=precision)
+    e.load_state_dict(synth.make_unet_weights(0, affine_jitter=True)); e.load_state_dict(synth.make_decoder_weights(0)); e.finalize()
+    w, wd = O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), O.to_torch(synth.make_decoder_weights(0))
+    inp, nz = synth.make_inputs(B, 7), synth.make_noise(B, n, 9)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    tgt = torch.from_numpy(synth.uniform(7, "tgt", (B, 52), 0.0, 12.0))
+    non_cond = torch.from_numpy(synth.normal(7, "non_cond_feat", (B, 256)))
+    x_T, z = torch.from_numpy(nz["x_T"]), torch.from_numpy(nz["noise"])
+    gd = {"curr_states": cs, "target_speed": tgt, "lr": 0.3, "optimizer": "adam"}
+    x0, _, _ = e.sample(x_T, cond, noise=z, non_cond=non_cond, guidance_w=2.0, guidance=gd)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(16, __import__("os").cpu_count() or 1))
+    try:
+        ref = O.sample_guided(w, wd, O.schedule(n), x_T, z, cond, cs, tgt, None, 0.3, "adam", non_cond, 2.0)["pred_traj"]
+    finally:
+        torch.set_num_threads(nthr)
+    scale = max(1.0, float(ref.abs().max()))
+    d = (x0.cpu() - ref).abs() / scale
+    assert float((d > 1e-3).float().mean()) <= 0.01, float(d.max())
+    plain, _, _ = e.sample(x_T, cond, noise=z, non_cond=non_cond, guidance_w=2.0)
+    g0, _, _ = e.sample(x_T, cond, noise=z, non_cond=non_cond, guidance_w=2.0, guidance=dict(gd, loss_scale=torch.zeros(B)))
+    assert torch.equal(plain, g0)
+
+
 def test_configs4_closed_loop_at_per_gpu_size(precision):
     """BASELINE configs[4] on one GPU's shard: 64 scenes x 64 = 4,096 agents, 50 denoising steps per planning call, the loop
     ContextEncoder-free (cond_feat supplied) -> sample -> decode -> VAE encode of the plan -> world update, 2 sim steps.
