@@ -450,7 +450,7 @@ def test_vae_forward_reconstruction_path():
 @pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
     """Target-speed + speed-limit + acceleration-limit guidance in one step against the reference's own perturb() (golden
-    'guidance', combo_sgd), through both formulations of the guidance kernel."""
+    'guidance', combo_sgd), through every formulation of the guidance kernel."""
     import os
     meta, g = golden("guidance")
     cond, cs, mean, tgt, _ = _guidance_inputs(meta)
