@@ -447,6 +447,28 @@ def test_vae_forward_reconstruction_path():
     assert (out["output"].cpu() - ref[..., :2]).abs().max().item() <= 2e-4 * max(1.0, ref[..., :2].abs().max().item())
 
 
+@pytest.mark.parametrize("B", [63, 64, 2048, 2049])
+def test_guidance_kernel_selection_boundaries(eng_jitter, B):
+    """The batch sizes either side of the rule that picks the guidance kernel (launch_guide: 2-agent VALU below 64 agents, 8
+    agents per workgroup up to 2,048, 16 agents per workgroup from 2,049): whatever the library picks must agree with the
+    16-agent kernel forced on the same inputs (the three formulations differ in summation order only)."""
+    inp = synth.make_inputs(B, 31)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    mean = torch.from_numpy(synth.normal(31, "guide_mean", (B, 52, 4)))
+    tgt = torch.from_numpy(synth.uniform(31, "guide_target_speed", (B, 52), 0.0, 12.0))
+    gd = {"curr_states": cs, "target_speed": tgt, "lr": 2.0, "perturb_th": None, "optimizer": "sgd"}
+    auto = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+    eng_jitter.force_kernel("guide", "mfma")
+    try:
+        ref = eng_jitter.guidance_step(mean, cond, gd, sigma=0.5, want_grad=True)
+        torch.cuda.synchronize()
+    finally:
+        eng_jitter.force_kernel("guide", "auto")
+    gmax = float(ref[1].abs().max())
+    assert float((auto[1] - ref[1]).abs().max()) <= 2e-5 * gmax
+    assert float((auto[0] - ref[0]).abs().max()) <= 2.0 * 4e-5 * gmax + 2.5e-7
+
+
 @pytest.mark.parametrize("kernel", ["valu", "mfma", "quad"])
 def test_guidance_combined_losses_golden(golden, eng_jitter, kernel):
     """Target-speed + speed-limit + acceleration-limit guidance in one step against the reference's own perturb() (golden
