@@ -1197,11 +1197,10 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wv8 & 3, kp = wv8 >> 2;          // unit group; K half = the agent quad whose cells this wave updates
-    const int ul = lane >> 2, q = lane & 3;         // MFMA lane roles: block ul; A row q (gate); B / D column q (agent of a quad)
-    const int u = 16 * wq + ul;                     // this lane's hidden unit; its cell: (u, agent 4 kp + q)
+    const int ul = lane >> 2, q = lane & 3;         // MFMA lane roles: block ul; A row q (agent of a quad); B / D column q (gate of unit ul)
+    const int u = 16 * wq + ul;                     // this lane's hidden unit; after the quad transpose its cell: (u, agent 4 kp + q)
     const int ao = 4 * kp + q;
     const float wa0 = w.w_h2a[u], wa1 = w.w_h2a[64 + u], bh2a = w.b_h2a[0], bh2b = w.b_h2a[1];
-    auto none = [](int) {};
 
     const int ngroups = (a.B + AG - 1) / AG;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void vae_loss_final_kernel(const float* __rest
     s0[threadIdx.x] = a; s1[threadIdx.x] = c;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
+        if ((int)threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
