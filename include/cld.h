@@ -343,7 +343,7 @@ int cld_debug_guide_stamps(void* out /*HOST, u64[2048]*/);
 int cld_debug_lds_floor(cld_handle h, size_t bytes);
 
 /* Tests only: force the formulation of one of the three recurrent kernels of this handle instead of letting the batch size
- * pick it (both forms compute the same function; the parity tests run each against the oracle).  The shipped library reads
+ * pick it (all forms compute the same function; the parity tests run each against the oracle).  The shipped library reads
  * no environment variable: every behaviour switch is an explicit call like this one. */
 #define CLD_KERNEL_GUIDE 0    /* guidance: LSTM forward + BPTT + roll-out backward (cld_sample_guided, cld_guidance_step) */
 #define CLD_KERNEL_DECODE 1   /* cld_lstm_decode, cld_decode */
