@@ -65,6 +65,7 @@ SIGNATURES = {
     "cld_sample_cfg": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, C.c_int32, C.c_uint64, _P, C.c_size_t, _P]),
     "cld_sample_guided": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.POINTER(CldGuidance), C.c_int32, _P, _P, _P, C.c_int32,
                                     C.c_uint64, _P, C.c_size_t, _P]),
+    "cld_sample_step": (C.c_int, [_P, _P, _P, _P, C.c_float, C.POINTER(CldGuidance), C.c_int32, _P, _P, _P, _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.c_size_t, _P]),
     "cld_guidance_step": (C.c_int, [_P, _P, _P, C.POINTER(CldGuidance), C.c_float, _P, _P, _P, _P, C.c_int32, _P, C.c_size_t, _P]),
     "cld_guidance_losses": (C.c_int, [_P, _P, C.POINTER(CldGuidance), _P, C.c_int32, _P]),
     "cld_log_prob": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, C.c_int32, _P, C.c_size_t, _P]),

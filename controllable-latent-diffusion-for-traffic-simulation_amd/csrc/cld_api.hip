@@ -1084,6 +1084,66 @@ int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx
     return CLD_OK;
 }
 
+static int check_guidance(cld_handle h, const char* fn, const cld_guidance* gd) {
+    if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
+    if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad))
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
+    if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
+    if (gd->apply_output && gd->final_optimizer != CLD_GUIDE_ADAM && gd->final_optimizer != CLD_GUIDE_SGD)
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer for the output step");
+    if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, std::string(fn) + ": target_pos_scale needs target_pos and target_time");
+    return CLD_OK;
+}
+
+// One iteration of the ancestral loop at timestep i on the latent in w.xw (CFG: rows [bp, 2 bp) hold the same latent, w.cb the
+// conditional / unconditional bias rows): U-Net, head (noise prediction -> posterior mean -> + sigma z), optional guidance step on
+// the mean.  Leaves x_{i-1} in w.xw (both halves) and, at i == 0 or on a guided step, the unguided posterior mean in w.meanb.
+// `z` is this step's noise slab (NULL: on-device generator keyed by (seed, salt)); mean_guided / grad (optional, [B,52,4]) receive
+// the guided mean and dL/dmean of a guided step.
+static int sample_iteration(cld_handle h, const Ws& w, bool cfg, int B, int bp, int i, const float* z, uint64_t seed,
+                            unsigned long long salt, const float* cond, float guidance_w, const cld_guidance* gd,
+                            float* mean_guided, float* grad, bool want_mean, hipStream_t s) {
+    const int bpn = cfg ? 2 * bp : bp;
+    float* x_hi = w.xw + (size_t)bp * T * D;
+    HIPCK(h, run_unet(h, w, w.xw, i, bpn, s));
+    const float sigma = std::exp(0.5f * h->plvc[i]);
+    // upstream defaults: apply_guidance_intermediate on, apply_guidance_output off (diffuser.py:876-881, scene_edit_config.py:84-85)
+    const bool guide = gd && (i > 0 ? !gd->no_intermediate : gd->apply_output != 0);
+    HeadArgs a{};
+    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
+    if (cfg) { a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w; }
+    a.z = z;
+    a.seed = seed; a.step_salt = salt;
+    a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
+    a.sg = (i == 0) ? 0.f : sigma;           // nonzero_mask, dm_model.py:151
+    if (guide) {
+        a.mean_out = w.meanb;                            // the guidance kernel perturbs the mean and adds the noise
+    } else {
+        a.x_out = w.xw;                                  // in place: each thread rewrites the row it read
+        a.x_out2 = cfg ? x_hi : nullptr;
+        a.mean_out = (i == 0 || want_mean) ? w.meanb : nullptr;
+    }
+    HIPCK(h, launch_head(a, s));
+    if (guide) {
+        GuideArgs g{};
+        g.mean = w.meanb; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed;
+        g.loss_scale = gd->loss_scale; g.z = a.z; g.x_out = w.xw; g.x_out2 = cfg ? x_hi : nullptr;
+        // a guided t = 0 step (apply_output): x0 IS the guided mean, and log_prob_final is taken around it (w.xtmp), not around the
+        // unguided mean it was stepped away from -- sigma_0 = 1e-10 would turn that step into ~ -1e18
+        g.mean_out = mean_guided ? mean_guided : (i == 0 ? w.xtmp : nullptr); g.grad_out = grad;
+        g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
+        g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
+        g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
+        g.ext_grad = gd->ext_grad;
+        // t = 0 (apply_guidance_output): the step's own optimiser settings, and no noise behind it (nonzero_mask, diffuser.py:929)
+        const float lr_in = i > 0 ? gd->lr : gd->final_lr, th_in = i > 0 ? gd->perturb_th : gd->final_perturb_th;
+        g.scratch = w.guide; g.lr = lr_in > 0.f ? lr_in : sigma; g.perturb_th = th_in > 0.f ? th_in : (th_in == 0.f ? sigma : -1.f);
+        g.sigma = a.sg; g.optimizer = i > 0 ? gd->optimizer : gd->final_optimizer; g.B = B; g.seed = seed; g.step_salt = salt;
+        HIPCK(h, launch_guide(h->dec, h->dyn, g, s, h->force_kernel[CLD_KERNEL_GUIDE]));
+    }
+    return CLD_OK;
+}
+
 static int sample_impl(cld_handle h, const char* fn, const float* x_T, const float* noise, const float* cond,
                        const float* non_cond, float guidance_w, const cld_guidance* gd, int32_t steps, float* x0, float* x1,
                        float* logp, int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream) {
@@ -1093,15 +1153,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
     if (!x_T || !cond) return fail(h, CLD_ERR_ARG, std::string(fn) + ": null pointer");
     if (steps != loop_steps(h))
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal len(range(0, n_timesteps, stride)) = " + std::to_string(loop_steps(h)));
-    if (gd) {
-        if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
-        if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad))
-            return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
-        if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
-        if (gd->apply_output && gd->final_optimizer != CLD_GUIDE_ADAM && gd->final_optimizer != CLD_GUIDE_SGD)
-            return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer for the output step");
-        if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, std::string(fn) + ": target_pos_scale needs target_pos and target_time");
-    }
+    if (gd && (rc = check_guidance(h, fn, gd)) != CLD_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // CFG: one 2B-agent batch per step: rows [0, bp) carry cond_feat, rows [bp, 2bp) the unconditional features,
     // both halves the same latent; the head combines the two noise predictions and rewrites both halves.
@@ -1116,45 +1168,40 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
     }
     for (int it = 0; it < steps; ++it) {
         const int i = (steps - 1 - it) * h->stride;
-        HIPCK(h, run_unet(h, w, w.xw, i, bpn, s));
-        const float sigma = std::exp(0.5f * h->plvc[i]);
-        // upstream defaults: apply_guidance_intermediate on, apply_guidance_output off (diffuser.py:876-881, scene_edit_config.py:84-85)
-        const bool guide = gd && (i > 0 ? !gd->no_intermediate : gd->apply_output != 0);
-        HeadArgs a{};
-        a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
-        if (cfg) { a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w; }
-        a.z = noise ? noise + (size_t)it * B * T * D : nullptr;
-        a.seed = seed; a.step_salt = (unsigned long long)it;
-        a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
-        a.sg = (i == 0) ? 0.f : sigma;
-        if (guide) {
-            a.mean_out = w.meanb;                            // the guidance kernel perturbs the mean and adds the noise
-        } else {
-            a.x_out = w.xw;                                  // in place: each thread rewrites the row it read
-            a.x_out2 = cfg ? x_hi : nullptr;
-            a.mean_out = (i == 0) ? w.meanb : nullptr;
-        }
-        HIPCK(h, launch_head(a, s));
-        if (guide) {
-            GuideArgs g{};
-            g.mean = w.meanb; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed;
-            g.loss_scale = gd->loss_scale; g.z = a.z; g.x_out = w.xw; g.x_out2 = cfg ? x_hi : nullptr;
-            g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
-            g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
-            g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
-            g.ext_grad = gd->ext_grad;
-            // t = 0 (apply_guidance_output): the step's own optimiser settings, and no noise behind it (nonzero_mask, diffuser.py:929)
-            const float lr_in = i > 0 ? gd->lr : gd->final_lr, th_in = i > 0 ? gd->perturb_th : gd->final_perturb_th;
-            g.scratch = w.guide; g.lr = lr_in > 0.f ? lr_in : sigma; g.perturb_th = th_in > 0.f ? th_in : (th_in == 0.f ? sigma : -1.f);
-            g.sigma = a.sg; g.optimizer = i > 0 ? gd->optimizer : gd->final_optimizer; g.B = B; g.seed = seed; g.step_salt = (unsigned long long)it;
-            HIPCK(h, launch_guide(h->dec, h->dyn, g, s, h->force_kernel[CLD_KERNEL_GUIDE]));
-        }
+        rc = sample_iteration(h, w, cfg, B, bp, i, noise ? noise + (size_t)it * B * T * D : nullptr, seed, (unsigned long long)it, cond,
+                              guidance_w, gd, nullptr, nullptr, false, s);
+        if (rc) return rc;
         if (i == 1 && x1) HIPCK(h, launch_unpack(w.xw, x1, B, s));
         if (i == 0) {
             if (x0) HIPCK(h, launch_unpack(w.xw, x0, B, s));
-            if (logp) HIPCK(h, launch_logprob(w.xw, w.meanb, sigma, logp, B, s));
+            if (logp) HIPCK(h, launch_logprob(w.xw, (gd && gd->apply_output) ? w.xtmp : w.meanb, std::exp(0.5f * h->plvc[0]), logp, B, s));
         }
     }
+    return CLD_OK;
+}
+
+int cld_sample_step(cld_handle h, const float* x_t, const float* cond, const float* non_cond, float guidance_w,
+                    const cld_guidance* gd, int32_t t_idx, const float* z, float* x_next, float* mean, float* mean_guided,
+                    float* grad, float* sigma_host, int32_t B, void* workspace, size_t workspace_bytes, void* stream) {
+    const bool cfg = non_cond != nullptr;
+    int rc = check_common(h, "cld_sample_step", cfg ? 2 * pad16(B) : B, t_idx, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!x_t || !cond || (!z && t_idx != 0)) return fail(h, CLD_ERR_ARG, "cld_sample_step: null pointer");
+    if (gd && (rc = check_guidance(h, "cld_sample_step", gd)) != CLD_OK) return rc;
+    if (sigma_host) *sigma_host = std::exp(0.5f * h->plvc[t_idx]);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int bp = pad16(B), bpn = cfg ? 2 * bp : bp;
+    Ws w = carve(workspace, bpn);
+    HIPCK(h, launch_pack_latent(x_t, w.xw, B, bp, s));
+    HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
+    if (cfg) {
+        HIPCK(h, launch_pack_latent(x_t, w.xw + (size_t)bp * T * D, B, bp, s));
+        HIPCK(h, launch_cond_bias(non_cond, h->wc, h->cbias_b, w.cb + (size_t)bp * NCB, B, bp, NCB, s));
+    }
+    rc = sample_iteration(h, w, cfg, B, bp, t_idx, z, 0, 0, cond, guidance_w, gd, mean_guided, grad, mean != nullptr, s);
+    if (rc) return rc;
+    if (x_next) HIPCK(h, launch_unpack(w.xw, x_next, B, s));
+    if (mean) HIPCK(h, launch_unpack(w.meanb, mean, B, s));
     return CLD_OK;
 }
 

@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
                 const int ks = (t * 2 + layer) * 5;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) kv[k] = kget(ks + k);
-                kv[5] = kget(ks - 10 + 4);      // the cell state of step t-1, same layer (t = 0: outside the buffer -> 0)
+                kv[5] = t > 0 ? kget(ks - 10 + 4) : 0.f;      // the cell state of step t-1, same layer; c_{-1} = 0 (t is wave-uniform)
             };
             auto grads = [&](const float (&kv)[6], float dh, float& dcn, float* row) {
                 const float i_ = kv[0], f_ = kv[1], g_ = kv[2], o_ = kv[3], c = kv[4], cp = kv[5];

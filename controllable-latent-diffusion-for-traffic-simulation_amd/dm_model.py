@@ -75,13 +75,17 @@ class _UnetSurface:
             x = x.reshape(BN * M, T, -1)
             cond = cond.reshape(BN * M, -1)
             time = time.repeat_interleave(M, dim=0)
-        time = torch.as_tensor(time).reshape(-1).to("cpu")
-        if time.numel() == 1:
-            time = time.expand(x.shape[0])
-        vals = torch.unique(time)
-        if vals.numel() == 1:
-            eps = self.engine.unet_forward(x, cond, int(vals[0]))
-        else:                                      # per-row timesteps: the time bias is folded per agent (cld_unet_forward_t)
+        if not torch.is_tensor(time) or time.device.type == "cpu":
+            # a Python int or host values: whether the batch shares one timestep is decided here, without a device round trip
+            tt = torch.as_tensor(time).reshape(-1)
+            if tt.numel() == 1 or bool((tt == tt[0]).all()):
+                eps = self.engine.unet_forward(x, cond, int(tt[0]))
+            else:
+                eps = self.engine.unet_forward_rows(x, cond, tt)
+        else:                                      # device tensor (0-dim or [B]): per-row path (the time bias is folded per agent,
+            time = time.reshape(-1)                    # cld_unet_forward_t); no .to("cpu") / unique, so no device sync per call
+            if time.numel() == 1:
+                time = time.expand(x.shape[0])
             eps = self.engine.unet_forward_rows(x, cond, time)
         return eps.reshape(BN, M, T, -1) if four_d else eps
 

@@ -159,13 +159,17 @@ class Engine:
         return eps
 
     def _timesteps(self, t, B: int) -> torch.Tensor:
-        """Per-row timesteps -> int32 [B] on the device, range-checked on the host (the kernels index tables with them)."""
-        t = torch.as_tensor(t).reshape(-1).to(torch.int64)
+        """Per-row timesteps -> int32 [B] on the device.  Host values (lists, CPU tensors) are range-checked here; a device
+        tensor is clamped to [0, n_timesteps) on the device instead, so the call stays asynchronous (the kernels index tables
+        with these values; training-style callers draw them with torch.randint on the device, dm_model.py:84)."""
+        t = torch.as_tensor(t).reshape(-1)
         if t.numel() != B:
             raise CldError(f"expected {B} timesteps, got {t.numel()}")
-        if t.numel() and (int(t.min()) < 0 or int(t.max()) >= self.n_timesteps):
-            raise CldError(f"timestep out of range [0, {self.n_timesteps})")
-        return t.to(self.device, torch.int32).contiguous()
+        if t.device.type == "cpu":
+            if t.numel() and (int(t.min()) < 0 or int(t.max()) >= self.n_timesteps):
+                raise CldError(f"timestep out of range [0, {self.n_timesteps})")
+            return t.to(self.device, torch.int32).contiguous()
+        return t.to(self.device).clamp(0, self.n_timesteps - 1).to(torch.int32).contiguous()
 
     def q_sample(self, z0, noise, t):
         """DmModel.q_sample (dm_model.py:91-96): sqrt(acp[t]) z0 + sqrt(1 - acp[t]) noise, per-row t."""
@@ -247,7 +251,7 @@ class Engine:
         fopt = (fo or {}).get("optimizer", "adam")
         if fopt not in _lib.OPTIMIZERS:
             raise CldError(f"unknown guidance optimizer '{fopt}' (adam | sgd)")
-        fth = (fo or {}).get("perturb_th", 1.0)
+        fth = (fo or {}).get("perturb_th", None)       # None = no clip: what upstream's perturb() does (guidance_loss.py:2237,2273-2276)
         cg = _lib.CldGuidance(cs.data_ptr(), None if ts is None else ts.data_ptr(), None if ls is None else ls.data_ptr(),
                               float(g["lr"]) if g.get("lr") else 0.0,
                               -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
@@ -366,6 +370,36 @@ class Engine:
                 self._check(self.lib.cld_sample(self._h, _ptr(x_T), _ptr(noise), _ptr(cond), n, _ptr(x0), _ptr(x1),
                                                 _ptr(logp), B, C.c_uint64(seed), ws, wsn, self._stream()), "cld_sample")
         return x0, x1, logp
+
+    def sample_step(self, x_t, cond, t_idx: int, z=None, non_cond=None, guidance_w: float = 0.0, guidance: Optional[Mapping] = None,
+                    want_grad: bool = False):
+        """One iteration of `sample` at timestep t_idx on a given x_t (cld_sample_step; upstream p_sample, diffuser.py:844-929)
+        -> dict(x_next, mean [posterior mean before guidance], sigma, and on a guided step mean_guided [, grad])."""
+        x_t = self._f32(x_t)
+        B = x_t.shape[0]
+        x_t = self._f32(x_t, (B, T, D)); cond = self._f32(cond, (B, COND))
+        z = None if z is None else self._f32(z, (B, T, D))
+        cfg = non_cond is not None and guidance_w != 0.0
+        non_cond = self._f32(non_cond, (B, COND)) if cfg else None
+        cg = keep = None
+        if guidance is not None:
+            cg, keep = self._guidance(guidance, B)
+        guided = guidance is not None and (bool(guidance.get("intermediate", True)) if t_idx > 0 else bool(guidance.get("output")))
+        xn, mean = torch.empty_like(x_t), torch.empty_like(x_t)
+        mg = torch.empty_like(x_t) if guided else None
+        gr = torch.empty_like(x_t) if guided and want_grad else None
+        ws, wsn = self._workspace(2 * ((B + 15) // 16 * 16) if cfg else B)
+        sigma = C.c_float()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_sample_step(self._h, _ptr(x_t), _ptr(cond), _ptr(non_cond), C.c_float(guidance_w),
+                                                 None if cg is None else C.byref(cg), int(t_idx), _ptr(z), _ptr(xn), _ptr(mean),
+                                                 _ptr(mg), _ptr(gr), C.byref(sigma), B, ws, wsn, self._stream()), "cld_sample_step")
+        out = {"x_next": xn, "mean": mean, "sigma": float(sigma.value)}
+        if guided:
+            out["mean_guided"] = mg
+            if want_grad:
+                out["grad"] = gr
+        return out
 
     def log_prob(self, x_t, x_tm1, cond, t_idx: int):
         x_t = self._f32(x_t)

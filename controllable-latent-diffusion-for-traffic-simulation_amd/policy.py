@@ -8,8 +8,10 @@ guidance active -- the one `choose_action_from_guidance` picks from the per-samp
 `obs_dict` is either the reference's observation batch (`image` [B,34,224,224], `history_positions`, `history_yaws`,
 `curr_speed`: the `ContextEncoder` of `context_utils.py` turns it into `cond_feat` / `curr_states` on the device), or
 already carries `cond_feat` [B,256] and `curr_states` [B,4]; a different `context_encoder` callable may be passed in.
-Parity: CLD itself never implemented `get_action`; the sample selection is pinned by a golden recorded from the reference's own
-`choose_action_from_guidance` / `choose_action_from_gt`, the composition and the world update are tested against
+Parity: CLD itself never implemented `get_action`; the sample selection by guidance loss is pinned by a golden recorded from the
+reference's own `choose_action_from_guidance` (`tests/golden/select.npz`).  `choose_action_from_gt` is a restatement of the
+evident intent and PARITY UNPINNED: the reference function reads an undefined name `T` and raises `NameError` as written
+(`guidance_loss.py:67-99`), so nothing could be recorded from it.  The composition and the world update are tested against
 `oracle/cld_oracle.py` (`get_action`, `world_step`: `env_trajdata.py:452-468`).
 """
 from __future__ import annotations

@@ -213,6 +213,19 @@ def make_unet_weights(seed: int = 0, affine_jitter: bool = False) -> "OrderedDic
     return out
 
 
+def perturb_unet_weights(w, seed: int, rel: float = 0.02, final_abs: float = 0.05) -> "OrderedDict[str, np.ndarray]":
+    """Weights "after an optimiser step" (the PPO update of src/trainers/guide_dm_trainer.py:127-183 moves every DM tensor
+    between sampling and `log_prob`): every tensor is moved by `rel` of its rms along a seeded normal direction, the output
+    layer `model.final_conv.1` by `final_abs` absolute -- enough that the t = 0 posterior mean moves by ~1e-2, far above the
+    fp32 rounding of O(1) latents (noise_cof[0] = 0.025 damps whatever the U-Net changes)."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, v in w.items():
+        rms = float(np.sqrt(np.mean(np.square(v, dtype=np.float64)))) if v.size else 0.0
+        step = final_abs if name.startswith("model.final_conv.1.") else rel * rms
+        out[name] = (v + step * normal(seed, "perturb:" + name, v.shape)).astype(np.float32)
+    return out
+
+
 def make_decoder_weights(seed: int = 0) -> "OrderedDict[str, np.ndarray]":
     """nn.LSTM init is U(+-1/sqrt(hidden)) for every tensor; Linear as above."""
     shapes = decoder_shapes()

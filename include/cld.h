@@ -203,9 +203,11 @@ typedef struct cld_guidance {
     const float* ext_grad;
     /* Guidance on the t = 0 OUTPUT of the chain (upstream `apply_guidance_output`, diffuser.py:877-880; off in upstream's
      * defaults, scene_edit_config.py:84-91): when non-zero the final posterior mean takes one optimiser step with its own
-     * settings (`final_step_opt_params`) and x0 is the guided mean (no noise is added at t = 0).  apply_intermediate == 0
-     * switches the per-step guidance at t > 0 off (upstream `apply_guidance_intermediate`); the struct zero-initialised keeps
-     * the defaults: intermediate on, output off.  Fields follow lr / perturb_th / optimizer above. */
+     * settings (`final_step_opt_params`) and x0 is the guided mean (no noise is added at t = 0).  no_intermediate != 0
+     * switches the per-step guidance at t > 0 off (upstream `apply_guidance_intermediate = False`); the struct zero-initialised
+     * keeps the defaults: intermediate on, output off.  Fields follow lr / perturb_th / optimizer above; final_perturb_th < 0 = no
+     * clip, which is what upstream's perturb() does (see the clipping note above).  The output step has no golden vector in the
+     * reference (off in every shipped config): PARITY UNPINNED beyond the oracle's restatement. */
     int32_t apply_output;
     int32_t no_intermediate;
     float final_lr;
@@ -217,6 +219,19 @@ typedef struct cld_guidance {
 int cld_sample_guided(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,
                       float guidance_w, const cld_guidance* guidance, int32_t steps, float* x0, float* x1, float* logp,
                       int32_t B, uint64_t seed, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ONE iteration of the loop of cld_sample / cld_sample_cfg / cld_sample_guided at timestep t_idx, teacher-forced: upstream's
+ * DiffuserModel.p_sample (src/tbsim/models/diffuser.py:844-929), CLD's DmModel.x_Tminus1 (models/dm/dm_model.py:144-156) when
+ * non_cond and guidance are NULL.  x_t [B,52,4] -> U-Net (twice with non_cond != NULL: eps = (1 + w) eps_c - w eps_u) ->
+ * posterior mean -> [guidance step on the mean when `guidance` is given and applies at this timestep] -> x_next = mean' + sigma_t z
+ * (no noise at t_idx == 0; z may then be NULL).  Outputs [B,52,4], any may be NULL: x_next; mean = the posterior mean BEFORE the
+ * guidance step; mean_guided and grad = dL/dmean are written only on a guided step; *sigma_host receives sigma_t = exp(0.5 *
+ * logvar[t_idx]) as the loop uses it.  Same kernels in the same order as the
+ * loop: stepping through t = n-1 .. 0 with the loop's noise slabs reproduces cld_sample* bit for bit.  Workspace as for the
+ * corresponding cld_sample* call (2 * pad16(B) agents with non_cond). */
+int cld_sample_step(cld_handle h, const float* x_t, const float* cond, const float* non_cond, float guidance_w,
+                    const cld_guidance* guidance, int32_t t_idx, const float* z, float* x_next, float* mean, float* mean_guided,
+                    float* grad, float* sigma_host /*HOST*/, int32_t B, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One guidance step on a given posterior mean [B,52,4] (teacher-forced form of the above, for tests and for callers that
  * drive the loop themselves): mean_guided = mean + clip(delta); x_next = mean_guided + sigma * z; grad = dL/dmean.

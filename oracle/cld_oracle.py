@@ -463,14 +463,17 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
 def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor,
                   loss_scale: Optional[Tensor] = None, lr: Optional[float] = 0.3, optimizer: str = "adam",
                   non_cond: Optional[Tensor] = None, guidance_w: float = 0.0, clip_to_sigma: bool = False,
-                  output: Optional[dict] = None) -> dict:
+                  output: Optional[dict] = None, taps: Optional[dict] = None) -> dict:
     """The ancestral loop of dm_model.py:119-132 with upstream's p_sample guidance (diffuser.py:844-929): steps t > 0
     perturb the posterior mean before the noise is added (lr None -> sigma_t); t = 0 is unguided unless `output` =
     dict(lr, optimizer) is given: upstream's apply_guidance_output with its final_step_opt_params (diffuser.py:877-880;
-    the perturb_th of those never acts, see guidance_step)."""
+    the perturb_th of those never acts, see guidance_step).  `taps` (a dict) receives `grads`: the list of (timestep, dL/dmean)
+    of every guided step -- the tests bound what Adam's sign-like step may do with them (`adam_step_budget`)."""
     n = sched["betas"].shape[0]
     x = x_T
     x1 = None
+    if taps is not None:
+        taps["grads"] = []
     for s_, i in enumerate(reversed(range(n))):
         t = torch.full((x.shape[0],), i, dtype=torch.long)
         eps = unet_forward(w, x, cond, t)
@@ -479,14 +482,47 @@ def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: 
         mean = sched["x_t_cof"][i] * x - sched["noise_cof"][i] * eps
         sigma = float((0.5 * sched["posterior_log_variance_clipped"][i]).exp())
         if i > 0:
-            mean, _ = guidance_step(wdec, mean, cond, cs, target_speed, loss_scale, sigma if lr is None else lr,
-                                    sigma if clip_to_sigma else None, optimizer)
+            mean, g_ = guidance_step(wdec, mean, cond, cs, target_speed, loss_scale, sigma if lr is None else lr,
+                                     sigma if clip_to_sigma else None, optimizer)
+            if taps is not None:
+                taps["grads"].append((i, g_))
         elif output is not None:
             mean, _ = guidance_step(wdec, mean, cond, cs, target_speed, loss_scale, output.get("lr", 0.3), None, output.get("optimizer", "adam"))
         x = mean + (0.0 if i == 0 else sigma) * noise[s_]
         if i == 1:
             x1 = x.clone()
     return {"pred_traj": x, "x1": x1}
+
+
+def sample_step(w, wdec, sched, x_t: Tensor, cond: Tensor, i: int, z: Optional[Tensor], non_cond: Optional[Tensor] = None,
+                guidance_w: float = 0.0, guidance: Optional[dict] = None) -> dict:
+    """ONE iteration of the loops above at timestep i on a given x_t (upstream p_sample, diffuser.py:844-929; with CFG and
+    guidance off it is DmModel.x_Tminus1, dm_model.py:144-156).  guidance = dict(curr_states, target_speed, loss_scale | None,
+    lr | None, optimizer).  -> dict(mean [before guidance], sigma, x_next, and on a guided step mean_guided, grad)."""
+    t = torch.full((x_t.shape[0],), i, dtype=torch.long)
+    eps = unet_forward(w, x_t, cond, t)
+    if non_cond is not None:
+        eps = (1 + guidance_w) * eps - guidance_w * unet_forward(w, x_t, non_cond, t)
+    mean = sched["x_t_cof"][i] * x_t - sched["noise_cof"][i] * eps
+    sigma = float((0.5 * sched["posterior_log_variance_clipped"][i]).exp())
+    out = {"mean": mean, "sigma": sigma}
+    m = mean
+    if guidance is not None and i > 0:
+        lr = guidance.get("lr")
+        m, g = guidance_step(wdec, mean, cond, guidance["curr_states"], guidance.get("target_speed"), guidance.get("loss_scale"),
+                             sigma if lr is None else lr, None, guidance.get("optimizer", "adam"))
+        out["mean_guided"], out["grad"] = m, g
+    out["x_next"] = m if (i == 0 or z is None) else m + sigma * z
+    return out
+
+
+def adam_step_budget(g: Tensor, lr: float, grad_tol: float) -> Tensor:
+    """How far Adam's first step delta(g) = -lr g / (|g| + 1e-8) (guidance_step) can move when the gradient is only known to
+    +-grad_tol: delta is monotone in g, so the worst case over [g - tol, g + tol] sits at an end point.  ~0 wherever
+    |g| >> grad_tol (the step is -lr sign(g) whatever the rounding), up to 2 lr where |g| <~ grad_tol (a sign flip).  Test
+    infrastructure: two correct fp32 implementations of the gradient agree to grad_tol, not to the bit."""
+    f = lambda v: v / (v.abs() + 1e-8)
+    return lr * torch.maximum(f(g + grad_tol) - f(g), f(g) - f(g - grad_tol))
 
 
 # --------------------------------------------------------------------------- #

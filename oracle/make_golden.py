@@ -60,9 +60,9 @@ def feed_noise(slabs):
         torch.randn, torch.randn_like = o_randn, o_like
 
 
-def build_dm(ref, n_timesteps, affine_jitter):
+def build_dm(ref, n_timesteps, affine_jitter, weights=None):
     dm = _refimport.quiet(ref.DmModel, ref.algo, None, n_timesteps=n_timesteps).eval()
-    w = synth.make_unet_weights(W_SEED, affine_jitter=affine_jitter)
+    w = weights if weights is not None else synth.make_unet_weights(W_SEED, affine_jitter=affine_jitter)
     sd = dm.state_dict()
     for k, v in w.items():
         assert tuple(sd[k].shape) == v.shape, (k, sd[k].shape, v.shape)
@@ -347,6 +347,63 @@ def section_small(ref):
          pred_traj=out["pred_traj"], x1=out["x1"], log_prob_final=out["log_prob_final"])
 
 
+def small_unet_weights():
+    """U-Net weights of the `sample_n100_small` chain: the output layer scaled by SMALL['final_scale']."""
+    w = synth.make_unet_weights(W_SEED, affine_jitter=True)
+    for k in ("model.final_conv.1.weight", "model.final_conv.1.bias"):
+        w[k] = (w[k] * np.float32(SMALL["final_scale"])).astype(np.float32)
+    return w
+
+
+PPO_PERTURB = dict(seed=77, rel=0.02, final_abs=0.05)
+
+
+def section_log_prob_t0(ref):
+    """DmModel.log_prob at the reference's ONLY call-site: t == 0 (src/trainers/guide_dm_trainer.py:160-164), where
+    sigma_0 = exp(0.5 * log(1e-20)) = 1e-10 and the value is -(x0 - mean)^2 / 2e-20 + const -- ~ -1e13 for a 1e-3 offset.
+    Two cases, both the reference's unmodified `dm.log_prob`:
+      t0   : the inputs of fixture `log_prob` (B = 4), x_tm1 = mean_ref + 1e-3 z;
+      ppo  : the PPO ratio term as the trainer forms it, M = 128: (x1, x0, log_prob_final) come from the reference's own
+             sampler (`dm(...)`, the O(1) chain of `sample_n100_small`, old weights), then log_prob(x1, x0, cond, t = 0) is
+             evaluated with the weights moved by an optimiser-step-like perturbation (synth.perturb_unet_weights)."""
+    out, meta = {}, {"w_seed": W_SEED, "affine_jitter": True, "in_seed": IN_SEED, "noise_seed": NOISE_SEED}
+    # ---- t0 ------------------------------------------------------------------------------
+    dm = build_dm(ref, 100, True)
+    B = 4
+    x_t = T(synth.normal(IN_SEED, "lp_xt", (B, 52, 4)))
+    cond = T(synth.make_inputs(B, IN_SEED)["cond_feat"])
+    t = torch.zeros(B, dtype=torch.long)
+    with torch.no_grad():
+        eps = dm.model(x_t, {"cond_feat": cond}, t)
+        mean, logvar = dm.x_tminus1_mean_var(x_t, eps, t)
+        x_tm1 = mean + 1e-3 * T(synth.normal(NOISE_SEED, "lp_z0_offset", (B, 52, 4)))
+        out["t0_x_tm1"] = x_tm1
+        out["t0_log_prob"] = dm.log_prob(x_t, x_tm1, {"cond_feat": cond}, t)
+        out["t0_sigma"] = (0.5 * logvar).exp().reshape(-1)[:1]
+    meta["t0"] = {"B": B, "x_t": "normal(in_seed,'lp_xt')", "offset": "1e-3 * normal(noise_seed,'lp_z0_offset')"}
+    # ---- ppo -----------------------------------------------------------------------------
+    M, n = 128, 100
+    w_old = small_unet_weights()
+    dm = build_dm(ref, n, True, weights=w_old)
+    inp = synth.make_inputs(M, IN_SEED)
+    nz = synth.make_noise(M, n, NOISE_SEED)
+    slabs = [T(nz["x_T"]) * SMALL["x_scale"]] + [T(nz["noise"][s]) * SMALL["noise_scale"] for s in range(n)]
+    with feed_noise(slabs):          # 1 thread like every fixture: the same-weights identity below holds only on identical arithmetic
+        smp = dm({"history_positions": torch.zeros(M, 31, 2)}, {"cond_feat": T(inp["cond_feat"])}, ref.algo)
+    x1, x0 = smp["x1"], smp["pred_traj"]
+    dm_new = build_dm(ref, n, True, weights=synth.perturb_unet_weights(w_old, **PPO_PERTURB))
+    t = torch.zeros(M, dtype=torch.long)
+    with torch.no_grad():
+        lp_new = dm_new.log_prob(x1, x0, {"cond_feat": T(inp["cond_feat"])}, t)
+        lp_same = dm.log_prob(x1, x0, {"cond_feat": T(inp["cond_feat"])}, t)       # old weights: x0 IS the mean -> log_prob_final
+    print("ppo: max|x1| =", float(x1.abs().max()), " log_p_new in", float(lp_new.min()), float(lp_new.max()),
+          " log_p_old =", float(smp["log_prob_final"][0]), " same-weights =", float(lp_same[0]))
+    out.update(ppo_x1=x1, ppo_x0=x0, ppo_log_prob_old=smp["log_prob_final"], ppo_log_prob_new=lp_new, ppo_log_prob_same=lp_same)
+    meta["ppo"] = dict({"M": M, "n_timesteps": n, "chain": "as sample_n100_small (SMALL scales), B = 128",
+                        "perturb": PPO_PERTURB}, **SMALL)
+    save("log_prob_t0", meta, **out)
+
+
 def section_select(ref):
     """Sample selection of upstream's get_action (algos.py:2053-2064): the reference's own `choose_action_from_guidance`
     (src/tbsim/utils/guidance_loss.py:22-66) on synthetic per-sample guidance losses.  Cases: two scenes with per-agent
@@ -410,7 +467,7 @@ def main():
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
             {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride, "losses": section_losses,
-             "n50": section_n50, "small": section_small, "select": section_select, "guide_losses": section_guide_losses}[name](ref)
+             "n50": section_n50, "small": section_small, "log_prob_t0": section_log_prob_t0, "select": section_select, "guide_losses": section_guide_losses}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
@@ -421,6 +478,7 @@ def main():
     section_losses(ref)
     section_n50(ref)
     section_small(ref)
+    section_log_prob_t0(ref)
     section_select(ref)
     section_guide_losses(ref)
 

@@ -118,6 +118,39 @@ def test_log_prob(golden):
     assert np.isfinite(lp0.numpy()).all() and np.isfinite(g["log_prob_t0"]).all()
 
 
+def _small_unet_weights(scale):
+    w = synth.make_unet_weights(0, affine_jitter=True)
+    for k in ("model.final_conv.1.weight", "model.final_conv.1.bias"):
+        w[k] = (w[k] * np.float32(scale)).astype(np.float32)
+    return w
+
+
+def test_log_prob_at_t0_vs_reference(golden):
+    """a-8 at the reference's only call-site, t == 0 (guide_dm_trainer.py:160-164): sigma_0 = 1e-10, the value is
+    -(x0 - mean)^2 / 2e-20 ~ -1e13..-1e15.  Relative bar 1e-3 (the offsets are 1e-3 / ~6e-3 on O(1) means: one ulp of the
+    mean moves a term by ~1e-4 relative)."""
+    meta, g = golden("log_prob_t0")
+    s = O.schedule(100)
+    assert float((0.5 * s["posterior_log_variance_clipped"][0]).exp()) == pytest.approx(1e-10, rel=1e-6)
+    assert float(g["t0_sigma"][0]) == pytest.approx(1e-10, rel=1e-6)                # not flushed: 1e-20 is a normal fp32
+    B = meta["t0"]["B"]
+    x_t = torch.from_numpy(synth.normal(meta["in_seed"], "lp_xt", (B, 52, 4)))
+    cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
+    lp = O.log_prob(W(True), s, x_t, torch.from_numpy(g["t0_x_tm1"]), cond, 0).numpy()
+    assert (g["t0_log_prob"] < -1e12).all()
+    assert np.abs(lp / g["t0_log_prob"] - 1.0).max() <= 1e-3
+    # PPO-shaped: (x1, x0) of a chain sampled with the old weights, log_prob under the perturbed ones
+    M = meta["ppo"]["M"]
+    cond = torch.from_numpy(synth.make_inputs(M, meta["in_seed"])["cond_feat"])
+    w_old = _small_unet_weights(meta["ppo"]["final_scale"])
+    w_new = O.to_torch(synth.perturb_unet_weights(w_old, **meta["ppo"]["perturb"]))
+    x1, x0 = torch.from_numpy(g["ppo_x1"]), torch.from_numpy(g["ppo_x0"])
+    lp = O.log_prob(w_new, s, x1, x0, cond, 0).numpy()
+    assert (g["ppo_log_prob_new"] < -1e14).all()
+    assert np.abs(lp / g["ppo_log_prob_new"] - 1.0).max() <= 1e-3
+    assert np.allclose(g["ppo_log_prob_old"], 22.106914, atol=1e-4) and np.array_equal(g["ppo_log_prob_same"], g["ppo_log_prob_old"])
+
+
 def test_decoder_and_dynamics(golden):
     meta, g = golden("decode")
     B = meta["B"]
