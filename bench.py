@@ -70,6 +70,8 @@ def main():
                     help="headline only: skip the secondary objects (configs1, f16x2 mode, ContextEncoder, configs3 / configs4 single-GPU anchors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event timing of the dominant kernel")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (backend nccl = RCCL) even at world size 1, so the collective path runs on a one-GPU box")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -87,10 +89,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     backend = None
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # "nccl" is RCCL on ROCm.  CLD_DIST_BACKEND=gloo only exists to rehearse the multi-process flow on a box
         # with fewer GPUs than ranks (ranks then share devices; the gather stages through the host).
@@ -171,6 +176,7 @@ def main():
         cs = torch.zeros(B, 4, device=dev)
         cs[:, 2] = torch.rand(B, device=dev, generator=g) * 15.0
         gathered = torch.empty(world * B, 52, 6, device=dev) if (distributed and even) else None
+        gathered_cl = torch.empty(world * B, 52 * 6 + 3, device=dev) if (distributed and even and wl["closed"]) else None
         guidance = None
         if wl["guide"]:   # upstream defaults: adam, lr 0.3, one gradient step per denoising step (scene_edit_config.py:74-90)
             guidance = {"curr_states": cs, "target_speed": torch.rand(B, 52, device=dev, generator=g) * 12.0,
@@ -184,17 +190,35 @@ def main():
             dmap = (torch.rand(B, 28, 28, device=dev, generator=g) > 0.2).repeat_interleave(8, dim=1).repeat_interleave(8, dim=2).to(torch.uint8)
             rfa = torch.tensor([[2.0, 0.0, 56.0], [0.0, 2.0, 112.0], [0.0, 0.0, 1.0]], device=dev).expand(B, 3, 3).contiguous()
             S = 8
-            opos = torch.randn(B, S, 52, 2, device=dev, generator=g) * 20.0
+            opos0 = torch.randn(B, S, 52, 2, device=dev, generator=g) * 20.0
             oav = torch.ones(B, S, 52, dtype=torch.uint8, device=dev)
+            # observation stand-in (the env is out of scope: env_trajdata.py:314-369 builds the neighbour tensors from ALL agents'
+            # poses): agent b's S neighbours are the next S agents of its scene, looked up in the GATHERED plans of the previous
+            # sim step at this rank's row offset -- so sim step s + 1 cannot start before the all-gather of step s has landed
+            row0 = sum(sizes[:rank])
+            ag = wl["agents"]
+            li = torch.arange(B, device=dev)
+            nb_idx = row0 + (li // ag)[:, None] * ag + (li % ag)[:, None].add(torch.arange(1, S + 1, device=dev)[None, :]).remainder(ag)   # [B,S]
 
-        def gather(traj):
+            def neighbours(plans_all, pose_all, pose_own):
+                """plans_all [B_all,52,6] agent-frame plans, pose_all [B_all,3] world poses they start from, pose_own [B,3] ->
+                the neighbours' planned positions in each agent's own frame [B,S,52,2]."""
+                pn, wn = plans_all[nb_idx][..., :2], pose_all[nb_idx]                    # [B,S,52,2], [B,S,3]
+                cn, sn = torch.cos(wn[..., 2])[..., None], torch.sin(wn[..., 2])[..., None]
+                wx = wn[..., 0:1] + cn * pn[..., 0] - sn * pn[..., 1]
+                wy = wn[..., 1:2] + sn * pn[..., 0] + cn * pn[..., 1]
+                dx, dy = wx - pose_own[:, None, 0:1], wy - pose_own[:, None, 1:2]
+                co, so = torch.cos(pose_own[:, 2])[:, None, None], torch.sin(pose_own[:, 2])[:, None, None]
+                return torch.stack([co * dx + so * dy, -so * dx + co * dy], dim=-1).contiguous()
+
+        def gather(traj, out=None):
             if not distributed:
                 return traj
-            return gather_trajectories(traj, gathered) if even else gather_ragged(traj, sizes)
+            return gather_trajectories(traj, gathered if out is None else out) if even else gather_ragged(traj, sizes)
 
         def one_step():
             if closed:      # rollout loop of env_utils.py:255-304 kept on the device (policy.closed_loop_rollout)
-                wpose, c = world0, cs
+                wpose, c, opos = world0, cs, opos0
                 for _ in range(closed):
                     cnd = eng.context_encode(raster, c) if ctx else cond      # obs -> cond_feat (context_utils.py:40-61)
                     x0, _, _ = eng.sample(x_T, cnd, noise=noise, non_cond=non_cond, guidance_w=wl["cfg_w"], want_x1=False, want_logp=False,
@@ -204,8 +228,11 @@ def main():
                     sa = eng.state_to_state_and_action(traj[..., :2].contiguous(), traj[..., 3:4].contiguous(), c[:, 2].contiguous(), scaled_output=True)
                     eng.traj2z(sa, cnd, noise=None)
                     eng.compute_reward(traj, sa, rfa, dmap, opos, oav)          # PPO reward of the plan (guide_dm_trainer.py:104)
-                    gather(traj)
-                    wpose, c = eng.world_step(traj, wpose[:, :2].contiguous(), wpose[:, 2].contiguous(), 4)
+                    # ONE all-gather per rollout step: plans and the poses they start from travel as one [B_local, 52*6 + 3] block
+                    both = gather(torch.cat([traj.reshape(B, -1), wpose], dim=1), gathered_cl)
+                    wpose_new, c = eng.world_step(traj, wpose[:, :2].contiguous(), wpose[:, 2].contiguous(), 4)
+                    opos = neighbours(both[:, :312].reshape(-1, 52, 6), both[:, 312:], wpose_new)     # next step's reward / observation input
+                    wpose = wpose_new
                 return traj
             x0, x1, logp = eng.sample(x_T, cond, noise=noise, non_cond=non_cond, guidance_w=wl["cfg_w"], guidance=guidance)
             traj = eng.decode(x0, cond, cs, descaled_output=True)
@@ -213,7 +240,12 @@ def main():
             return traj
 
         for _ in range(warmup):
-            one_step()
+            if closed and wl.get("warm_closed"):      # a warm-up of `warm_closed` sim steps instead of a whole closed-loop pass
+                full, closed = closed, wl["warm_closed"]
+                one_step()
+                closed = full
+            else:
+                one_step()
         fence()
         if profile:
             eng.profile_enable(True)
@@ -236,13 +268,15 @@ def main():
                 ach = flop / (ms * 1e-3) / 1e12
                 split = eng.precision == "f16x2"      # 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi) per algorithmic product
                 peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+                traffic = pmc_traffic(rows) if not split else (None, None)
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": pmc_traffic(rows) if not split else None,
+                        "frac": round(ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],
                         "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                        else "v_mfma_f32_16x16x4_f32 dense peak"),
                         "kernel": ("conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0,0> (Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; "
-                                   "8 launches per U-Net evaluation -- 7 with 256 input channels, 1 with 128 -- every 10th evaluation timed; "
-                                   "tiling picked by the rows per launch)" % ("4,1" if rows >= 2048 else ("4,2" if rows >= 1024 else "2,2"))),
+                                   "7 launches per U-Net evaluation, all with 256 input channels (the 128 -> 256 block opens with a pair "
+                                   "launch of its own kernel) -- every 10th evaluation timed; tiling picked by the rows per launch)"
+                                   % ("4,1" if rows >= 2048 else ("4,2" if rows >= 1024 else "2,2"))),
                         "agents_per_launch": rows, "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
                         "flop_per_launch": flop / launches}
         units = B_total * n * steps * max(1, closed)
@@ -340,8 +374,8 @@ def main():
         secondary("configs3_one_gpu", lambda: sec_workload(
             "configs3", 1, 1, note="the N = 1 point of the strong-scaling job that `bench.py --gpus N` runs for N > 1 (65,536 agents on one GPU)"))
         secondary("configs4_one_gpu_shard", lambda: sec_workload(
-            "configs4", 1, 0, use_ctx=use_ctx, scenes=64, closed=5,
-            note="one GPU's shard of configs[4] (64 of 512 scenes = 4,096 agents), 5 of the 20 sim steps, no warm-up pass"))
+            "configs4", 1, 1, use_ctx=use_ctx, scenes=64, closed=5, warm_closed=1,
+            note="one GPU's shard of configs[4] (64 of 512 scenes = 4,096 agents), 5 of the 20 sim steps timed after one warm-up sim step"))
     if extras and use_ctx and name in ("configs1", "configs2"):
         def ctx_extra():
             # ContextEncoder measured on its own (it runs once per planning call, not per denoising step): 1,024 agents, rasters
@@ -386,19 +420,20 @@ def main():
 
 
 def pmc_traffic(rows):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
-    gfx950 correction + WRITE_SIZE, profiles/run_r*.sh); PMC cannot be collected inside this process, so
-    the number is the committed one for the same kernel and the same rows per launch, else null."""
+    """-> (HBM bytes per launch of the dominant kernel, the committed file they come from): rocprofv3 PMC passes (FETCH_SIZE x2
+    per the gfx950 correction + WRITE_SIZE, profiles/run_r*.sh).  PMC cannot be collected inside this process, so the number is
+    the committed one for the same kernel and the same rows per launch -- NOT measured in this run (`traffic_source` says which
+    file) -- else (None, None)."""
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic*.json")), reverse=True):
             with open(f) as fh:
                 t = json.load(fh)
             if int(t.get("batch_agents", -1)) == rows:
-                return int(t["hbm_bytes_per_launch"])
+                return int(t["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT) + " (committed rocprofv3 PMC pass; not collected in this run)"
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def host_cores():

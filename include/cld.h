@@ -337,8 +337,9 @@ int cld_world_step(cld_handle h, const float* traj, const float* centroid, const
 
 /* Measurement aid for bench.py (no reference counterpart): while enabled, every launch of the
  * dominant kernel instance -- the Conv1d(k=5) + GroupNorm + Mish block producing 256 channels at
- * L = 13 (conv_block_kernel<13,13,1,5,32,*,*,1,32,1,0,0,0>: 7 launches with 256 input channels and one with
- * 128 per U-Net evaluation, temporal.py:16-45) -- in every 10th U-Net evaluation is bracketed by HIP events on the
+ * L = 13 (conv_block_kernel<13,13,1,5,32,*,*,1,32,1,0,0,0>: 7 launches per U-Net evaluation, all with 256 input
+ * channels -- the 128 -> 256 block opens with a pair launch of its own kernel; temporal.py:16-45) -- in every 10th U-Net
+ * evaluation is bracketed by HIP events on the
  * caller's stream (a sample: an event pair costs ~2 us of stream time, so timing all of them would slow the region measured).
  * cld_profile_read waits for the recorded events and returns the summed kernel time, the
  * number of launches and their algorithmic FLOP (2 * rows * K * N); enable(…, 1) resets. */

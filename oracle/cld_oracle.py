@@ -516,6 +516,22 @@ def sample_step(w, wdec, sched, x_t: Tensor, cond: Tensor, i: int, z: Optional[T
     return out
 
 
+def speed_kink_margin(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor, dyn: dict = DYN) -> Tensor:
+    """Per agent [B]: how close the decoded speed chain of `mean` comes to a point where the target-speed guidance loss is not
+    differentiable -- |v_t - target_t| (the loss's own kink, guidance_loss.py:219-254), the speed clip and the acceleration clip
+    of the roll-out (diffuser_helpers.py:557-559,573-576).  Two correct implementations that disagree in the last bits of v
+    may land on different sides of such a point and then differ by a whole term of the gradient; the tests hold agents
+    with a margin below their trajectory tolerance to a bound instead of to 2e-5 (test infrastructure)."""
+    std = torch.tensor(NORM_STD, dtype=mean.dtype)
+    mu = torch.tensor(NORM_MEAN, dtype=mean.dtype)
+    acc = lstm_decode(wdec, mean, cond)[..., 0] * std[4] + mu[4]
+    v_raw = torch.cumsum(torch.cat((cs[:, 2:3], acc.clamp(dyn["acce_lo"], dyn["acce_hi"]) * dyn["dt"]), dim=1), dim=1)[:, 1:]
+    v = v_raw.clamp(dyn["v_lo"], dyn["v_hi"])
+    m = torch.minimum((v - target_speed).abs(), torch.minimum((v_raw - dyn["v_lo"]).abs(), (v_raw - dyn["v_hi"]).abs()))
+    m = torch.minimum(m, torch.minimum((acc - dyn["acce_lo"]).abs(), (acc - dyn["acce_hi"]).abs()) * dyn["dt"])
+    return m.amin(dim=1)
+
+
 def adam_step_budget(g: Tensor, lr: float, grad_tol: float) -> Tensor:
     """How far Adam's first step delta(g) = -lr g / (|g| + 1e-8) (guidance_step) can move when the gradient is only known to
     +-grad_tol: delta is monotone in g, so the worst case over [g - tol, g + tol] sits at an end point.  ~0 wherever

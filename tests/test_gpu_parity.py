@@ -382,9 +382,9 @@ def test_guided_chain_vs_oracle(eng10):
             x = got["x_next"]
         x0, _, _ = eng10.sample(x_T, cond, noise=z, non_cond=nc, guidance_w=cfg_w, guidance=gd)
         assert torch.equal(x0, x)
-        sgd = dict(gd, lr=20.0, optimizer="sgd")
+        sgd = dict(gd, lr=2000.0, optimizer="sgd")
         x0, _, _ = eng10.sample(x_T, cond, noise=z, non_cond=nc, guidance_w=cfg_w, guidance=sgd)
-        ref = O.sample_guided(w, wd, O.schedule(n), x_T.cpu(), z.cpu(), cond.cpu(), cs.cpu(), tgt.cpu(), None, 20.0, "sgd",
+        ref = O.sample_guided(w, wd, O.schedule(n), x_T.cpu(), z.cpu(), cond.cpu(), cs.cpu(), tgt.cpu(), None, 2000.0, "sgd",
                               None if nc is None else nc.cpu(), cfg_w)
         scale = max(1.0, float(ref["pred_traj"].abs().max()))
         assert float((x0.cpu() - ref["pred_traj"]).abs().max()) <= 1e-3 * scale
@@ -769,8 +769,8 @@ def test_sample_with_caller_defined_loss(eng10):
     x_T, z = torch.from_numpy(nz["x_T"]).cuda(), torch.from_numpy(nz["noise"]).cuda()
     loss = lambda tr: (tr[..., 2] - tgt).abs().mean(dim=1).sum()
     # SGD (no sign function in the step): the two routes to the same gradient must agree end to end on all elements
-    builtin, _, _ = eng10.sample(x_T, cond, noise=z, guidance={"curr_states": cs, "target_speed": tgt, "lr": 20.0, "optimizer": "sgd"})
-    custom, x1 = eng10.sample_with_loss(x_T, cond, cs, z, loss, lr=20.0, optimizer="sgd")
+    builtin, _, _ = eng10.sample(x_T, cond, noise=z, guidance={"curr_states": cs, "target_speed": tgt, "lr": 2000.0, "optimizer": "sgd"})
+    custom, x1 = eng10.sample_with_loss(x_T, cond, cs, z, loss, lr=2000.0, optimizer="sgd")
     scale = max(1.0, float(builtin.abs().max()))
     assert float((custom - builtin).abs().max()) <= 1e-3 * scale
     assert x1 is not None

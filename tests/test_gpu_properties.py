@@ -390,7 +390,7 @@ def test_configs2_guided_cfg_chain_every_step_vs_oracle(precision):
 def test_configs2_guided_cfg_chain_sgd_all_elements(precision):
     """The same chain with SGD (delta = -lr g: no sign function, nothing to flip): end to end against the oracle's autograd
     restatement with the strict bar on ALL 425,984 latent elements."""
-    n, lr = 6, 20.0
+    n, lr = 6, 2000.0          # |g| <~ 4e-3: steps of up to ~8 per element, far above the bar the result is held to
     O, e, w, wd, d = _configs2(precision, n)
     gd = {"curr_states": d["cs"], "target_speed": d["tgt"], "lr": lr, "optimizer": "sgd"}
     x0, x1, _ = e.sample(d["x_T"], d["cond"], noise=d["z"], non_cond=d["non_cond"], guidance_w=2.0, guidance=gd)
@@ -402,7 +402,7 @@ def test_configs2_guided_cfg_chain_sgd_all_elements(precision):
     err = float((x0.cpu() - ref["pred_traj"]).abs().max())
     moved = float((ref["pred_traj"] - unguided).abs().max())
     print(f"SGD chain: max|d| {err:.3e} of max|x0| {scale:.3e}; guidance moved x0 by up to {moved:.3e}")
-    assert moved > 50 * 1e-3 * scale                  # the guidance term is far above the bar it is checked to
+    assert moved > 20 * 1e-3 * scale                  # the guidance term is far above the bar it is checked to
     assert err <= 1e-3 * scale
     assert float((x1.cpu() - ref["x1"]).abs().max()) <= 1e-3 * scale
 
@@ -484,3 +484,65 @@ def test_configs4_closed_loop_at_per_gpu_size(precision):
     assert float((poses[:, idx] - poses_s).abs().max()) <= 2e-3 * max(1.0, float(poses.abs().max()))
     again, _ = run(None)
     assert torch.equal(again, poses)                   # deterministic
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (e) multi-GPU: the RCCL branch, executed (world size 1 is all a one-GPU box can offer)
+# ---------------------------------------------------------------------------------------------------------
+def _child(args, env_extra, timeout=600):
+    """Run a fresh python child (the GPU is initialised by this process already; nothing is exec'ed over it)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    return subprocess.run([sys.executable] + args, env=env, capture_output=True, text=True, timeout=timeout,
+                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def test_rccl_all_gather_on_device_tensors(precision):
+    """`torch.distributed` backend "nccl" (= RCCL on ROCm) initialised with a device id, `all_gather_into_tensor` and the padded
+    ragged gather of cld_amd.parallel on DEVICE tensors: executed once, at world size 1 (the driver's 8-GPU run is the first
+    time more ranks exist).  The reference has no counterpart (single device, utils/trainer_utils.py:122-141)."""
+    if precision != "f32":
+        pytest.skip("precision-independent")
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "from cld_amd.parallel import gather_trajectories, gather_ragged\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group(backend='nccl', device_id=torch.device('cuda', 0))\n"
+        "assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+        "t = torch.randn(4096, 52, 6, device='cuda')\n"
+        "out = torch.empty(4096, 52, 6, device='cuda')\n"
+        "g = gather_trajectories(t, out)\n"
+        "assert g.data_ptr() == out.data_ptr() and torch.equal(g, t)\n"
+        "r = gather_ragged(t[:1000], [1000])\n"
+        "assert torch.equal(r, t[:1000])\n"
+        "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group(); print('RCCL_OK')\n")
+    p = _child(["-c", code], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541", "RANK": "0", "WORLD_SIZE": "1"})
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_bench_distributed_branch_runs_on_rccl(precision):
+    """bench.py's distributed branch (init_process_group("nccl", device_id=...), the all-gather inside the timed region, the
+    max-over-ranks reduction) on a real device: `--force-dist` at world size 1 must report backend nccl and land within 5 % of
+    the same run without torch.distributed (configs[2], 2 timed steps; boxes repeat to ~1.5 %).  The closed loop (configs[4]
+    shard, 2 sim steps) runs with the neighbours of sim step s + 1 read from the tensor the all-gather of step s filled."""
+    import json
+    if precision != "f32":
+        pytest.skip("precision-independent")
+    common = ["bench.py", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--no-profile"]
+    plain = _child(common, {})
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    forced = _child(common + ["--force-dist"], {"MASTER_PORT": "29542"})
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    a, b = json.loads(plain.stdout.strip().splitlines()[-1]), json.loads(forced.stdout.strip().splitlines()[-1])
+    assert "distributed" not in a
+    assert b["distributed"]["backend"] == "nccl" and b["distributed"]["world_size_seen"] == 1
+    print("configs2 plain", a["value"], "forced-dist", b["value"])
+    assert abs(b["value"] / a["value"] - 1.0) <= 0.05
+    closed = _child(["bench.py", "--workload", "configs4", "--scenes", "16", "--closed-loop", "2", "--steps", "1", "--warmup", "1", "--no-extras",
+                     "--no-cpu-baseline", "--no-profile", "--force-dist"], {"MASTER_PORT": "29543"})
+    assert closed.returncode == 0, closed.stderr[-2000:]
+    c = json.loads(closed.stdout.strip().splitlines()[-1])
+    assert c["distributed"]["backend"] == "nccl" and c["value"] > 0
