@@ -49,7 +49,7 @@ struct cld_handle_s {
     cld_config cfg{};
     int stride = 1;                                  // DmModel.stride (dm_model.py:25,119): the loop visits i = ..., 2 stride, stride, 0
     int precision = CLD_PRECISION_F32;               // cfg.precision
-    int force_kernel[3] = {0, 0, 0};                 // cld_debug_force_kernel: formulation of the guide / decode / encode kernels (0 = by batch size)
+    int force_kernel[4] = {0, 0, 0, 0};              // cld_debug_force_kernel: formulation of the guide / decode / encode kernels and of the U-Net's layer chains (0 = by batch size)
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
     std::map<std::string, size_t> expect;            // name -> numel
@@ -62,6 +62,8 @@ struct cld_handle_s {
     ResBlock blocks[12];
     ConvLayer down[2], upT[2][2], final_cb;
     float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr, *res4_w = nullptr, *res4_b = nullptr;
+    float* head_wfrag = nullptr;        // final_conv.1 as an MFMA N tile (the tail chain of conv_chain.hip)
+    bool eps_in_buf7 = false;           // the last run_unet left the noise prediction [b_pad,52,4] in buf[7] (chains) instead of final_conv.0's activations
     DecoderWeights dec{};
     EncoderWeights enc{};
     bool has_encoder = false;
@@ -441,6 +443,16 @@ hipError_t run_args(cld_handle h, const ConvLayer& l, ConvArgs a, int b_pad, hip
     return launch_maybe_timed(h, l, g, a, b_pad, s);
 }
 
+// The 64-channel levels as LDS-resident layer chains (conv_chain.hip): exact-fp32 handles only; by default from the batch size
+// at which a chain launch (4 agents per workgroup) fills the chip's workgroup slots.
+bool use_chains(cld_handle h, int b_pad) {
+    if (h->precision != CLD_PRECISION_F32) return false;
+    const int f = h->force_kernel[CLD_KERNEL_UNET];
+    if (f == CLD_FORM_LAYERS) return false;
+    if (f == CLD_FORM_CHAIN) return true;
+    return b_pad >= 1024;
+}
+
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
 // final_conv.0 activations [b_pad,52,64] in w.buf[7].
 hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_pad, hipStream_t s) {
@@ -465,6 +477,29 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         return hipSuccess;
     };
 #define RB(...) do { e = resblock(__VA_ARGS__); if (e != hipSuccess) return e; } while (0)
+    if (use_chains(h, b_pad)) {
+        // downs.0 (five layers at 64 channels x 52 rows) as one launch, the tile resident in LDS (conv_chain.hip)
+        ChainHeadArgs ca{};
+        ca.x = x;
+        auto stage = [&](const ConvLayer& l, int res_kind, int keep) {
+            ChainStage st{};
+            st.wfrag = l.wfrag; st.bias = l.bias; st.gamma = l.gamma; st.beta = l.beta; st.cb_off = l.cb_off;
+            st.res_kind = res_kind; st.keep = keep;
+            return st;
+        };
+        ca.st[0] = stage(h->blocks[0].c0, CHAIN_RES_NONE, 0);
+        ca.st[1] = stage(h->blocks[0].c1, CHAIN_RES_LATENT, 1);
+        ca.st[2] = stage(h->blocks[1].c0, CHAIN_RES_NONE, 0);
+        ca.st[3] = stage(h->blocks[1].c1, CHAIN_RES_KEPT, 0);
+        ca.st[4] = stage(h->down[0], CHAIN_RES_NONE, 0);
+        ca.res4_w = h->res4_w; ca.res4_b = h->res4_b;
+        ca.cbias = w.cb; ca.cb_stride = NCB; ca.tbias = tbr;
+        ca.keep = b[2]; ca.y = b[6];
+        ca.stamps = (h->stamp_buf && h->stamp_layer == 0) ? h->stamp_buf : nullptr;
+        h->launch_counter += 5;
+        e = launch_chain_head(ca, b_pad, s);
+        if (e != hipSuccess) return e;
+    } else {
     {   // block 0: conv(4 -> 64) | conv(64 -> 64) + residual_conv(x), the 1x1 projection of the latent evaluated in the epilogue
         RC(h->blocks[0].c0, x, nullptr, b[1], nullptr);
         ConvArgs a1 = make_args(h, h->blocks[0].c1, b[1], nullptr, b[2], nullptr, w.cb, tbr);
@@ -474,6 +509,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     }
     RB(h->blocks[1], b[2], nullptr, b[3]);
     RC(h->down[0], b[3], nullptr, b[6], nullptr);
+    }
     RB(h->blocks[2], b[6], nullptr, b[2]);
     RB(h->blocks[3], b[2], nullptr, b[4]);            // skip 128@26
     RC(h->down[1], b[4], nullptr, b[6], nullptr);
@@ -486,15 +522,52 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     e = run_pair(h, h->upT[0][0], make_args(h, h->upT[0][0], b[6], nullptr, b[3], nullptr, w.cb, tbr),
                  h->upT[0][1], make_args(h, h->upT[0][1], b[6], nullptr, b[3], nullptr, w.cb, tbr), b_pad, s);   // 128@26
     if (e != hipSuccess) return e;
+    h->eps_in_buf7 = false;
+    if (use_chains(h, b_pad)) {
+        // ups.1.0's first conv + residual projection as one pair launch (K = 256 x 5 from HBM), then everything behind it --
+        // ups.1.0's second conv, ups.1.1, the transposed conv, final_conv.0 and final_conv.1 -- as one launch (conv_chain.hip)
+        const ResBlock& rb = h->blocks[10];
+        e = run_pair(h, rb.c0, make_args(h, rb.c0, b[3], b[4], b[1], nullptr, w.cb, tbr),
+                     rb.res, make_args(h, rb.res, b[3], b[4], b[0], nullptr, w.cb, tbr), b_pad, s);
+        if (e != hipSuccess) return e;
+        auto stage = [&](const ConvLayer& l, int res_kind, int keep, const float* res) {
+            ChainStage st{};
+            st.wfrag = l.wfrag; st.bias = l.bias; st.gamma = l.gamma; st.beta = l.beta; st.cb_off = l.cb_off;
+            st.res_kind = res_kind; st.keep = keep; st.res = res;
+            return st;
+        };
+        ChainTailArgs ct{};
+        ct.x = b[1];
+        ct.st[0] = stage(rb.c1, CHAIN_RES_TENSOR, 1, b[0]);
+        ct.st[1] = stage(h->blocks[11].c0, CHAIN_RES_NONE, 0, nullptr);
+        ct.st[2] = stage(h->blocks[11].c1, CHAIN_RES_KEPT, 0, nullptr);
+        ct.up_even = stage(h->upT[1][0], CHAIN_RES_NONE, 0, nullptr);
+        ct.up_odd = stage(h->upT[1][1], CHAIN_RES_NONE, 0, nullptr);
+        ct.fin = stage(h->final_cb, CHAIN_RES_NONE, 0, nullptr);
+        ct.head_wfrag = h->head_wfrag; ct.head_b = h->head_b;
+        ct.cbias = w.cb; ct.cb_stride = NCB; ct.tbias = tbr;
+        ct.keep = b[2]; ct.eps = b[7];
+        h->launch_counter += 6;
+        e = launch_chain_tail(ct, b_pad, s);
+        if (e != hipSuccess) return e;
+        h->eps_in_buf7 = true;
+    } else {
     RB(h->blocks[10], b[3], b[4], b[2]);              // cat(x, skip) 256@26 -> 64@26
     RB(h->blocks[11], b[2], nullptr, b[6]);
     e = run_pair(h, h->upT[1][0], make_args(h, h->upT[1][0], b[6], nullptr, b[3], nullptr, w.cb, tbr),
                  h->upT[1][1], make_args(h, h->upT[1][1], b[6], nullptr, b[3], nullptr, w.cb, tbr), b_pad, s);   // 64@52
     if (e != hipSuccess) return e;
     RC(h->final_cb, b[3], nullptr, b[7], nullptr);
+    }
 #undef RB
 #undef RC
     return hipSuccess;
+}
+
+// what the head kernel reads after run_unet: final_conv.0's activations, or the noise prediction itself when the tail chain ran
+inline void head_source(cld_handle h, const Ws& w, HeadArgs& a) {
+    if (h->eps_in_buf7) a.eps_in = w.buf[7];
+    else a.f = w.buf[7];
 }
 
 // loop iterations of the sampler: len(range(0, n_timesteps, stride)) (dm_model.py:119)
@@ -577,7 +650,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 2 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 3 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }
@@ -793,6 +866,10 @@ int cld_finalize(cld_handle h, void* stream) {
     }
     UP(h->head_w, *getw(h, "model.final_conv.1.weight"));
     UP(h->head_b, *getw(h, "model.final_conv.1.bias"));
+    {   // final_conv.1 [4,64,1] as one 16-column N tile of the chain kernel (columns 4..15 zero)
+        const std::vector<float>& W = *getw(h, "model.final_conv.1.weight");
+        UP(h->head_wfrag, pack_conv_weights([&](int co, int ci, int) { return co < 4 ? W[(size_t)co * 64 + ci] : 0.f; }, 16, 64, 1));
+    }
     return CLD_OK;
     };
     if (h->has_unet) {
@@ -1016,7 +1093,7 @@ int cld_unet_forward(cld_handle h, const float* x, const float* cond, int32_t t_
     HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
     HIPCK(h, run_unet(h, w, w.xw, t_idx, bp, s));
     HeadArgs a{};
-    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
+    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
     HIPCK(h, launch_head(a, s));
     return CLD_OK;
 }
@@ -1034,7 +1111,7 @@ int cld_unet_forward_t(cld_handle h, const float* x, const float* cond, const in
     HIPCK(h, launch_add_time_bias(w.cb, h->tb, t_idx, h->cfg.n_timesteps, B, NCB, s));
     HIPCK(h, run_unet(h, w, w.xw, -1, bp, s));
     HeadArgs a{};
-    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
+    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = eps; a.B = B; a.b_pad = bp;
     HIPCK(h, launch_head(a, s));
     return CLD_OK;
 }
@@ -1054,7 +1131,7 @@ int cld_denoise_loss(cld_handle h, const float* z0, const float* noise, const fl
     HIPCK(h, launch_add_time_bias(w.cb, h->tb, t_idx, h->cfg.n_timesteps, B, NCB, s));
     HIPCK(h, run_unet(h, w, w.xw, -1, bp, s));
     HeadArgs a{};
-    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = w.xtmp; a.B = B; a.b_pad = bp;
+    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.eps_out = w.xtmp; a.B = B; a.b_pad = bp;
     HIPCK(h, launch_head(a, s));
     HIPCK(h, launch_mse_rows(noise, w.xtmp, mse, B, s));
     return CLD_OK;
@@ -1074,7 +1151,7 @@ int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx
     HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, B, bp, NCB, s));
     HIPCK(h, run_unet(h, w, w.xw, t_idx, bp, s));
     HeadArgs a{};
-    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.z = z; a.B = B; a.b_pad = bp;
+    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.z = z; a.B = B; a.b_pad = bp;
     a.mean_out = w.meanb; a.x_out = w.xtmp;
     a.xc = h->x_t_cof[t_idx]; a.nc = h->noise_cof[t_idx];
     a.sg = (t_idx == 0) ? 0.f : sigma;       // nonzero_mask, dm_model.py:151
@@ -1110,8 +1187,12 @@ static int sample_iteration(cld_handle h, const Ws& w, bool cfg, int B, int bp, 
     // upstream defaults: apply_guidance_intermediate on, apply_guidance_output off (diffuser.py:876-881, scene_edit_config.py:84-85)
     const bool guide = gd && (i > 0 ? !gd->no_intermediate : gd->apply_output != 0);
     HeadArgs a{};
-    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
-    if (cfg) { a.f_uncond = w.buf[7] + (size_t)bp * T * 64; a.cfg_w = guidance_w; }
+    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
+    if (cfg) {
+        if (a.eps_in) a.eps_in_uncond = a.eps_in + (size_t)bp * T * D;
+        else a.f_uncond = w.buf[7] + (size_t)bp * T * 64;
+        a.cfg_w = guidance_w;
+    }
     a.z = z;
     a.seed = seed; a.step_salt = salt;
     a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
@@ -1278,7 +1359,7 @@ int cld_log_prob(cld_handle h, const float* x_t, const float* x_tm1, const float
     HIPCK(h, launch_cond_bias(cond, h->wc, h->cbias_b, w.cb, M, bp, NCB, s));
     HIPCK(h, run_unet(h, w, w.xw, t_idx, bp, s));
     HeadArgs a{};
-    a.f = w.buf[7]; a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = M; a.b_pad = bp;
+    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = M; a.b_pad = bp;
     a.mean_out = w.meanb; a.xc = h->x_t_cof[t_idx]; a.nc = h->noise_cof[t_idx];
     HIPCK(h, launch_head(a, s));
     HIPCK(h, launch_logprob(x_tm1, w.meanb, std::exp(0.5f * h->plvc[t_idx]), out, M, s));

@@ -76,6 +76,49 @@ bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
 void set_lds_floor(size_t bytes);      // experiments only: minimum dynamic LDS per conv launch (0 = off)
 
 // ---------------------------------------------------------------------------
+// layer chains (conv_chain.hip): runs of 64-channel layers in one launch, the tile resident in LDS from layer to layer
+// ---------------------------------------------------------------------------
+enum { CHAIN_RES_NONE = 0, CHAIN_RES_LATENT = 1 /* residual_conv(latent), evaluated in the epilogue */,
+       CHAIN_RES_KEPT = 2 /* the block input kept by an earlier stage */, CHAIN_RES_TENSOR = 3 /* [b_pad, L, 64] in HBM */ };
+struct ChainStage {
+    const float* wfrag;   // pack_conv_weights layout (pack_latent_conv_weights for the latent's conv)
+    const float* bias;    // [64]
+    const float* gamma;   // GroupNorm weight / bias (null for bias-only stages)
+    const float* beta;
+    const float* res;     // CHAIN_RES_TENSOR
+    int cb_off;           // >= 0: columns of the time / cond vectors added after Mish; -1 none
+    int res_kind;
+    int keep;             // 1: this stage's output is a later stage's CHAIN_RES_KEPT residual
+};
+struct ChainHeadArgs {    // downs.0.0 + downs.0.1 + downs.0.2: latent [b_pad,52,4] -> y [b_pad,26,64]
+    const float* x;
+    ChainStage st[5];     // conv 4->64 | conv 64->64 (+ residual_conv(latent), kept) | conv | conv (+ kept) | Conv1d k3 s2
+    const float* res4_w;  // residual_conv of block 0: [64][4], [64]
+    const float* res4_b;
+    const float* cbias;   // per-agent vectors [b_pad][cb_stride]
+    int cb_stride;
+    const float* tbias;   // per-step vector, or null (per-agent timesteps: folded into cbias)
+    float* keep;          // b_pad * 3328 floats of per-thread spill (one activation buffer)
+    float* y;
+    unsigned long long* stamps;   // diagnostic builds (-DCLD_STAMPS) only: 16 u64 per workgroup; null otherwise
+};
+hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, hipStream_t s);
+struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_conv: x [b_pad,26,64] -> eps [b_pad,52,4]
+    const float* x;       // output of ups.1.0's first conv
+    ChainStage st[3];     // conv (+ residual tensor = residual_conv of the block input, kept) | conv | conv (+ kept)
+    ChainStage up_even, up_odd;   // ConvTranspose1d as two 2-tap parity convolutions (wfrag, bias)
+    ChainStage fin;       // final_conv.0
+    const float* head_wfrag;      // final_conv.1 [4,64,1] as one 16-column N tile in pack_conv_weights layout (columns 4..15 zero)
+    const float* head_b;          // [4]
+    const float* cbias;
+    int cb_stride;
+    const float* tbias;
+    float* keep;          // b_pad * 1792 floats of per-thread spill
+    float* eps;           // [b_pad,52,4] noise prediction
+};
+hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // small kernels (misc_kernels.hip)
 // ---------------------------------------------------------------------------
 // x [B,52,4] -> xw [B_pad,52,4] (rows >= B zero-filled)
@@ -96,7 +139,9 @@ hipError_t launch_vae_loss(const float* x6, const float* act, const float* mu, c
 hipError_t launch_mse_rows(const float* a, const float* b, float* out, int B, hipStream_t s);
 // head: eps = W f + b (64 -> 4); mean = xc*x - nc*eps; x' = mean + sg*z
 struct HeadArgs {
-    const float* f;      // [B_pad,52,64]
+    const float* eps_in; // [B_pad,52,4]: the noise prediction itself (the tail chain of conv_chain.hip has applied final_conv.1), or null
+    const float* eps_in_uncond;   // its unconditional half in CFG mode
+    const float* f;      // [B_pad,52,64] (eps_in == null)
     const float* w;      // [4,64]
     const float* b;      // [4]
     const float* x;      // [B_pad,52,4] current latent

@@ -1,0 +1,508 @@
+// conv_chain.hip -- runs of 64-channel layers of TemporalMapUnet as ONE launch each, the activations never leaving the CU.
+//
+// At the 64-channel levels of the U-Net (reference: src/tbsim/models/temporal.py:148-176; L = 52: downs.0.*, final_conv;
+// L = 26: ups.1.*) one conv workgroup owns whole agents AND every output channel, so the output tile of one layer IS the
+// input tile of the next: nothing but the kernel boundary forced it through HBM.  conv_block_kernel runs these layers at
+// 62-71 % of the fp32-MFMA peak at 4,096 rows (a third of each workgroup's life is entry latency + write-through stores at
+// the HBM rate); the chains below keep the tile in LDS from layer to layer:
+//
+//   chain_head_kernel :  latent [B,52,4] -> downs.0.0 (conv 4->64 | conv 64->64 + residual_conv(latent)) -> downs.0.1
+//                        (two convs, identity residual) -> downs.0.2 (Conv1d k3 s2) -> [B,26,64]            5 launches -> 1
+//                        (the skip h[0] the reference pushes here is never popped, temporal.py:155,164: nothing else leaves)
+//   chain_tail_kernel :  ups.1.0's second conv -> ups.1.1 -> ups.1.2 (ConvTranspose1d k4 s2) -> final_conv.0 -> final_conv.1
+//                        (1x1, 64 -> 4): [B,26,64] -> eps [B,52,4]                                          6 launches -> 1
+//
+// Same arithmetic as conv_block.hip: v_mfma_f32_16x16x4_f32 (exact fp32), the same k order per accumulator (chunk of 32
+// channels, tap, 16-channel group), two-pass GroupNorm statistics, Mish by one v_exp_f32 + one v_rcp_f32.  What differs:
+//   * the A image holds ALL input channels of the tile (rows of 64 + 8 floats), written once by the previous layer's
+//     epilogue; the K loop touches HBM / L2 only for its weight fragments (one coalesced 1-KiB load per 52 MFMAs);
+//   * GroupNorm + Mish run on the accumulators IN REGISTERS: under the transposed M-tile mapping (M-tile m = rows
+//     RPT m .. of every agent, conv_block.hip TMAP) register r of a lane is agent r, and a group's 8 channels x L rows are
+//     13 registers x 8 lanes x 4 lane groups -- five cross-lane steps per pass instead of a tile exchange through LDS;
+//   * a block's input (the identity residual two layers later) waits in a per-thread spill slot in the workspace.
+#include "cld_kernels.h"
+
+#ifndef CLD_STORE_AUX
+#define CLD_STORE_AUX 16
+#endif
+
+namespace cld {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+#ifdef CLD_STAMPS
+// diagnostic build: in-kernel cycle stamps (never compiled into the shipped library)
+#define CSTAMP(k)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (p.stamps && tid == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                          \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define CSTAMP_RT(k)                                                                               \
+    do {                                                                                           \
+        if (p.stamps && tid == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                          \
+        }                                                                                          \
+    } while (0)
+#else
+#define CSTAMP(k) do {} while (0)
+#define CSTAMP_RT(k) do {} while (0)
+#endif
+
+namespace {
+
+__device__ __forceinline__ float mish_c(float x) {      // conv_block.hip mish_f
+    const float e = __expf(fminf(x, 30.0f));
+    const float n = e * (e + 2.0f);
+    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+}
+__device__ __forceinline__ v4f bload16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// Geometry of a 64-channel tile of AG agents x L rows.  LDS image: rows of KCP floats; agent a's rows start at a * ASTR,
+// two zero rows lead every agent block (the next agent's lead rows are the previous one's trailing halo), AEX extra floats
+// per block keep the fragment reads conflict-free (scripts/lds_conflicts.py: L = 52 -> 0, L = 26 -> 16).
+template <int L_, int AG_>
+struct Geo {
+    static constexpr int C = 64, L = L_, AG = AG_;
+    static constexpr int KCP = C + 8;
+    static constexpr int LP = L + 2;
+    static constexpr int AEX = (L == 26) ? 16 : 0;
+    static constexpr int ASTR = LP * KCP + AEX;
+    static constexpr int RPT = 16 / AG;                 // rows of one agent per M-tile
+    static constexpr int NMT = (AG * L + 15) / 16;
+    static constexpr bool RAGGED = NMT * RPT != L;      // the last M-tile carries rows past the agent's end
+    static_assert(AG == 4, "register r = agent r (AG = 4) is what the in-register epilogue assumes");
+};
+constexpr int kImgFloats = (4 * 54 + 2 + 6) * 72;      // the L = 52 image + 6 slack rows (stride-2 / ragged fragment reads run past the last agent)
+static_assert(kImgFloats >= 4 * Geo<26, 4>::ASTR + 8 * 72, "the L = 26 image fits in the same allocation");
+
+// K loop over an LDS-resident image: acc[m] += sum over (chunk c, tap t, group g) in conv_block.hip's order.
+// abase: byte address of this lane's fragment for (M-tile 0, tap 0, channel group 0); M-tile m is MSTEP bytes further.
+template <int KCP, int MSTEP, int C_IN, int NTAPS, int NMT>
+__device__ __forceinline__ void kloop(v4f (&acc)[NMT], const char* ldsb, const int abase, const __amdgpu_buffer_rsrc_t rsw,
+                                      const int wlane, const int ntn, const int ntile) {
+    constexpr int NIT = (C_IN / 16) * NTAPS;
+    auto loff = [](int it) {                 // LDS byte offset of iteration it = (chunk, tap, group)
+        const int c = it / (2 * NTAPS), ii = it % (2 * NTAPS), t = ii / 2, g = ii % 2;
+        return (t * KCP + 16 * (2 * c + g)) * 4;
+    };
+    auto wload = [&](int it) {
+        const int c = it / (2 * NTAPS), ii = it % (2 * NTAPS), t = ii / 2, g = ii % 2;
+        return bload16(rsw, wlane, (((2 * c + g) * NTAPS + t) * ntn + ntile) * 1024);
+    };
+    v4f bq0 = wload(0), bq1 = wload(1);
+    v4f af[2][NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + abase + m * MSTEP + loff(0));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int cur = it & 1;
+        const v4f bcur = bq0;
+        bq0 = bq1;
+        if (it + 2 < NIT) bq1 = wload(it + 2);
+#pragma unroll
+        for (int g = 0; g < NMT; ++g) {
+            if (it + 1 < NIT) af[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + abase + g * MSTEP + loff(it + 1 < NIT ? it + 1 : 0));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = 4 * g + q, sidx = idx / NMT, m = idx % NMT;
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][m][sidx], bcur[sidx], acc[m], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// sum over the 8 lanes of a GroupNorm group (channels) and the 4 lane groups (rows) that hold one agent's values
+__device__ __forceinline__ float group_sum(float s) {
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return s;
+}
+
+// GroupNorm(8 channels x L rows per agent, eps 1e-5, biased variance; diffuser_helpers.py:61) + Mish + per-agent vector, on the
+// accumulators of one wave: lane (n, q) register r of M-tile m = (agent r, row RPT m + q, channel 16 wave + n).
+template <class G>
+__device__ __forceinline__ void gn_mish(v4f (&acc)[G::NMT], const float bias, const float gam, const float bet, const float (&add)[4], const int q) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < G::NMT; ++m) {
+        const bool ok = !G::RAGGED || m < G::NMT - 1 || G::RPT * m + q < G::L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[m][r] += bias;
+            s[r] += ok ? acc[m][r] : 0.f;
+        }
+    }
+    float mean[4], sc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mean[r] = group_sum(s[r]) * (1.0f / (float)(8 * G::L));
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < G::NMT; ++m) {
+        const bool ok = !G::RAGGED || m < G::NMT - 1 || G::RPT * m + q < G::L;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = acc[m][r] - mean[r];
+            ss[r] += ok ? d * d : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sc[r] = (1.0f / sqrtf(group_sum(ss[r]) * (1.0f / (float)(8 * G::L)) + 1e-5f)) * gam;
+#pragma unroll
+    for (int m = 0; m < G::NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][r] = mish_c((acc[m][r] - mean[r]) * sc[r] + bet) + add[r];
+}
+
+// accumulators -> the image rows of the next layer (every lane one float per (M-tile, agent): 64-byte runs per lane group)
+template <class G>
+__device__ __forceinline__ void to_image(const v4f (&acc)[G::NMT], float* lds, const int wbase, const int q) {
+#pragma unroll
+    for (int m = 0; m < G::NMT; ++m) {
+        if (G::RAGGED && m == G::NMT - 1 && G::RPT * m + q >= G::L) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[wbase + r * G::ASTR + G::RPT * m * G::KCP] = acc[m][r];
+    }
+}
+
+template <class G>
+__device__ __forceinline__ void zero_halo(float* lds, const int tid, const int nthr) {
+    // the two leading rows and, behind every agent, its two halo rows (+ the AEX floats, + the slack rows behind the last agent)
+    constexpr int GQ = (2 * G::KCP + G::AEX) / 4;
+    for (int i = tid; i < (G::AG + 1) * GQ; i += nthr) {
+        const int qd = i % GQ, g = i / GQ;
+        if (g == 0 && qd >= 2 * G::KCP / 4) continue;
+        const int at = g == 0 ? 0 : (g - 1) * G::ASTR + (2 + G::L) * G::KCP;
+        *reinterpret_cast<v4f*>(lds + at + qd * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// downs.0 as one launch
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs p) {
+    typedef Geo<52, 4> G;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xl = lds + kImgFloats;                        // the tile's latent rows [4][52][4]: operand of residual_conv in stage 1
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * 4;
+    const int n = 16 * wave + n16;                       // this lane's output channel
+    CSTAMP(0);
+    CSTAMP_RT(14);
+
+    // ---- latent rows -> image channel slots 0..3 (+ a compact copy); halos zeroed once: no layer writes them ----
+    if (tid < 208) {
+        const int a = tid / 52, l = tid % 52;
+        const v4f v = *reinterpret_cast<const v4f*>(p.x + ((size_t)(b0 + a) * 52 + l) * 4);
+        *reinterpret_cast<v4f*>(lds + a * G::ASTR + (2 + l) * G::KCP) = v;
+        *reinterpret_cast<v4f*>(xl + tid * 4) = v;
+    }
+    zero_halo<G>(lds, tid, 256);
+    for (int i = tid; i < 6 * G::KCP / 4; i += 256)      // slack rows behind the image (read by the stride-2 layer's last M-tile, never used)
+        *reinterpret_cast<v4f*>(lds + (4 * 54 + 2) * G::KCP + i * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+
+    v4f acc[G::NMT];
+    // fragment base of this lane: agent n16 % 4, row n16 / 4 of M-tile 0; lane group q takes channels 4q.. of a 16-channel group
+    const int arow = (n16 % 4) * G::ASTR + (n16 / 4) * G::KCP;                 // floats, relative to the agent block's row 0 (= first halo row)
+    const int wbase = (2 + q) * G::KCP + n;                                    // epilogue: (agent 0, row q, channel n)
+    constexpr int MSTEP = G::RPT * G::KCP * 4;
+
+    // ---- stage 0: Conv1d(4 -> 64, k5) with K folded over (tap, channel) (conv_block.hip PADC) ----
+    {
+        const ChainStage& st = p.st[0];
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 2048, 0x00020000);
+        const v4f bq0 = bload16(rsw, lane * 32, wave * 2048), bq1 = bload16(rsw, lane * 32 + 16, wave * 2048);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
+        const int ab = (arow + q * G::KCP) * 4;                                // row j + kk - 2 + 2 of tap kk = q, channels 0..3
+        const int t4 = ((4 - q) * G::KCP + q) * 4;                             // -> (row of tap 4, channel q)
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) {
+            const v4f a4 = *reinterpret_cast<const v4f*>(ldsb + ab + m * MSTEP);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sidx], bq0[sidx], acc[m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(ldsb + ab + m * MSTEP + t4), bq1[0], acc[m], 0, 0, 0);
+        float add[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + r) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
+        gn_mish<G>(acc, st.bias[n], st.gamma[n], st.beta[n], add, q);
+        __syncthreads();                                 // every wave has read the latent slots
+        to_image<G>(acc, lds, wbase, q);
+        __syncthreads();
+    }
+    CSTAMP(1);
+
+    // ---- stages 1..3: Conv1d(64 -> 64, k5) + GroupNorm + Mish [+ time / cond vector] [+ residual]; one code instance ----
+    v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * 13 * 256 + tid;
+#pragma clang loop unroll(disable)
+    for (int s = 1; s <= 3; ++s) {
+        const ChainStage& st = p.st[s];
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
+        kloop<G::KCP, MSTEP, 64, 5, G::NMT>(acc, ldsb, (arow + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        CSTAMP(2 * s);
+        float add[4] = {0.f, 0.f, 0.f, 0.f};
+        if (st.cb_off >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + r) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
+        }
+        gn_mish<G>(acc, st.bias[n], st.gamma[n], st.beta[n], add, q);
+        if (st.res_kind == CHAIN_RES_LATENT) {
+            // residual_conv = Conv1d(4 -> 64, k = 1) of the block input, the latent (temporal.py:32-34)
+            const v4f w4 = *reinterpret_cast<const v4f*>(p.res4_w + (size_t)n * 4);
+            const float b4 = p.res4_b[n];
+#pragma unroll
+            for (int m = 0; m < G::NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const v4f x4 = *reinterpret_cast<const v4f*>(xl + (r * 52 + 4 * m + q) * 4);
+                    acc[m][r] += b4 + w4[0] * x4[0] + w4[1] * x4[1] + w4[2] * x4[2] + w4[3] * x4[3];
+                }
+        } else if (st.res_kind == CHAIN_RES_KEPT) {
+#pragma unroll
+            for (int m = 0; m < G::NMT; ++m) {
+                const v4f k4 = keep[m * 256];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][r] += k4[r];
+            }
+        }
+        if (st.keep) {
+#pragma unroll
+            for (int m = 0; m < G::NMT; ++m) keep[m * 256] = acc[m];
+        }
+        __syncthreads();                                 // every wave is done reading the image this layer consumed
+        to_image<G>(acc, lds, wbase, q);
+        __syncthreads();
+        CSTAMP(2 * s + 1);
+    }
+
+    // ---- stage 4: Conv1d(64 -> 64, k3, stride 2, pad 1) + bias -> [B,26,64]; rows 4m + q < 26 of each agent ----
+    {
+        typedef Geo<26, 4> GO;
+        const ChainStage& st = p.st[4];
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 3 * 4 * 1024, 0x00020000);
+        v4f acd[GO::NMT];
+#pragma unroll
+        for (int m = 0; m < GO::NMT; ++m) acd[m] = v4f{0.f, 0.f, 0.f, 0.f};
+        // input row of tap 0 = 2 j - 1 (+ 2 halo rows): agent n16 % 4, j = 4 m + n16 / 4
+        kloop<G::KCP, 2 * MSTEP, 64, 3, GO::NMT>(acd, ldsb, ((n16 % 4) * G::ASTR + (1 + 2 * (n16 / 4)) * G::KCP + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        CSTAMP(8);
+        const float bias = st.bias[n];
+        const size_t ybase = (size_t)b0 * 26 * 64;
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y + ybase, 0, 4 * 26 * 64 * 4, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < GO::NMT; ++m) {
+            if (m == GO::NMT - 1 && 4 * m + q >= 26) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acd[m][r] + bias), rsy, ((r * 26 + 4 * m + q) * 64 + n) * 4, 0, CLD_STORE_AUX);
+        }
+    }
+    CSTAMP(9);
+    CSTAMP_RT(15);
+}
+
+hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
+    constexpr size_t lds_bytes = sizeof(float) * (kImgFloats + 4 * 52 * 4);
+    static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups per CU");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (b_pad % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_head_kernel, dim3(b_pad / 4), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ups.1.0's second conv + ups.1.1 + ups.1.2 + final_conv as one launch
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs p) {
+    typedef Geo<26, 4> G;          // stages 0..2 and the transposed conv's input
+    typedef Geo<52, 4> H;          // its output, final_conv
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * 4;
+    const int n = 16 * wave + n16;
+
+    // ---- input rows [4 agents][26][64] -> image (coalesced 256-byte rows) ----
+    {
+        const v4f* src = reinterpret_cast<const v4f*>(p.x + (size_t)b0 * 26 * 64);
+        v4f st[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int idx = tid + 256 * i;
+            st[i] = src[idx < 1664 ? idx : tid];
+        }
+        zero_halo<G>(lds, tid, 256);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 1664) {
+                const int row = idx >> 4, a = row / 26, l = row - a * 26;
+                *reinterpret_cast<v4f*>(lds + a * G::ASTR + (2 + l) * G::KCP + (idx & 15) * 4) = st[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    const int arow = (n16 % 4) * G::ASTR + (n16 / 4) * G::KCP;
+    const int wbase = (2 + q) * G::KCP + n;
+    constexpr int MSTEP = 4 * G::KCP * 4;
+    v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * 7 * 256 + tid;
+    v4f acc[G::NMT];
+
+    // ---- stages 0..2: Conv1d(64 -> 64, k5) + GroupNorm + Mish at L = 26 (6.5 M-tiles: rows 4 m + q >= 26 of the last one are dummies) ----
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < 3; ++s) {
+        const ChainStage& st = p.st[s];
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
+        kloop<G::KCP, MSTEP, 64, 5, G::NMT>(acc, ldsb, (arow + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        float add[4] = {0.f, 0.f, 0.f, 0.f};
+        if (st.cb_off >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + r) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
+        }
+        gn_mish<G>(acc, st.bias[n], st.gamma[n], st.beta[n], add, q);
+        if (st.res_kind == CHAIN_RES_TENSOR) {
+            const float* rp = st.res + ((size_t)b0 * 26 + q) * 64 + n;
+#pragma unroll
+            for (int m = 0; m < G::NMT; ++m) {
+                if (m == G::NMT - 1 && 4 * m + q >= 26) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][r] += rp[(r * 26 + 4 * m) * 64];
+            }
+        } else if (st.res_kind == CHAIN_RES_KEPT) {
+#pragma unroll
+            for (int m = 0; m < G::NMT; ++m) {
+                const v4f k4 = keep[m * 256];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][r] += k4[r];
+            }
+        }
+        if (st.keep) {
+#pragma unroll
+            for (int m = 0; m < G::NMT; ++m) keep[m * 256] = acc[m];
+        }
+        __syncthreads();
+        to_image<G>(acc, lds, wbase, q);
+        __syncthreads();
+    }
+
+    // ---- ConvTranspose1d(64 -> 64, k4, s2, p1) as two 2-tap parity convolutions: out[2j] = x[j-1] W3 + x[j] W1,
+    //      out[2j+1] = x[j] W2 + x[j+1] W0 (conv_block.hip); both from the L = 26 image, then the tile becomes an L = 52 image ----
+    {
+        v4f ae[G::NMT], ao[G::NMT];
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) { ae[m] = v4f{0.f, 0.f, 0.f, 0.f}; ao[m] = v4f{0.f, 0.f, 0.f, 0.f}; }
+        const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up_even.wfrag), 0, 4 * 2 * 4 * 1024, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up_odd.wfrag), 0, 4 * 2 * 4 * 1024, 0x00020000);
+        kloop<G::KCP, MSTEP, 64, 2, G::NMT>(ae, ldsb, (arow + 1 * G::KCP + 4 * q) * 4, rse, lane * 16, 4, wave);    // tap 0 reads x[j - 1] = image row 2 + j - 1
+        kloop<G::KCP, MSTEP, 64, 2, G::NMT>(ao, ldsb, (arow + 2 * G::KCP + 4 * q) * 4, rso, lane * 16, 4, wave);    // tap 0 reads x[j]
+        const float be = p.up_even.bias[n], bo = p.up_odd.bias[n];
+        __syncthreads();                                 // the L = 26 image is dead
+        zero_halo<H>(lds, tid, 256);
+        const int wb = (2 + 2 * q) * H::KCP + n;         // (agent 0, row 2 (0 + q), channel n)
+#pragma unroll
+        for (int m = 0; m < G::NMT; ++m) {
+            if (m == G::NMT - 1 && 4 * m + q >= 26) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lds[wb + r * H::ASTR + 8 * m * H::KCP] = ae[m][r] + be;
+                lds[wb + r * H::ASTR + (8 * m + 1) * H::KCP] = ao[m][r] + bo;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- final_conv.0: Conv1d(64 -> 64, k5) + GroupNorm + Mish at L = 52 ----
+    const int hrow = (n16 % 4) * H::ASTR + (n16 / 4) * H::KCP;
+    constexpr int HSTEP = 4 * H::KCP * 4;
+    {
+        v4f af[H::NMT];
+#pragma unroll
+        for (int m = 0; m < H::NMT; ++m) af[m] = v4f{0.f, 0.f, 0.f, 0.f};
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.fin.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
+        kloop<H::KCP, HSTEP, 64, 5, H::NMT>(af, ldsb, (hrow + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        const float add[4] = {0.f, 0.f, 0.f, 0.f};
+        gn_mish<H>(af, p.fin.bias[n], p.fin.gamma[n], p.fin.beta[n], add, q);
+        __syncthreads();
+        to_image<H>(af, lds, (2 + q) * H::KCP + n, q);
+        __syncthreads();
+    }
+
+    // ---- final_conv.1: Conv1d(64 -> 4, k1): one N tile (4 of its 16 columns real); wave w takes M-tiles w, w + 4, w + 8 (, 12) ----
+    {
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.head_wfrag), 0, 4 * 1024, 0x00020000);
+        v4f bw[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[g] = bload16(rsw, lane * 16, g * 1024);
+        const int ab = (hrow + 2 * H::KCP + 4 * q) * 4 + wave * HSTEP;       // the centre tap: image row 2 + j
+        v4f ah[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) ah[mi] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if (mi == 3 && wave != 0) continue;          // M-tile 12 is wave 0's
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4f a4 = *reinterpret_cast<const v4f*>(ldsb + ab + mi * 4 * HSTEP + g * 64);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) ah[mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sidx], bw[g][sidx], ah[mi], 0, 0, 0);
+            }
+        }
+        if (n16 < 4) {
+            const float hb = p.head_b[n16];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if (mi == 3 && wave != 0) continue;
+                const int pos = 4 * (wave + 4 * mi) + q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.eps[((size_t)(b0 + r) * 52 + pos) * 4 + n16] = ah[mi][r] + hb;
+            }
+        }
+    }
+}
+
+hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, hipStream_t s) {
+    constexpr size_t lds_bytes = sizeof(float) * kImgFloats;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (b_pad % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_tail_kernel, dim3(b_pad / 4), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cld

@@ -182,15 +182,28 @@ hipError_t launch_vae_loss(const float* x6, const float* act, const float* mu, c
 
 // head: eps = W f + b (final_conv.1, temporal.py:119) ; mean = xc*x - nc*eps ; x' = mean + sg*z
 // one thread per (b, l) row: reads 64 channels (256 B), writes 4 values.
+// With eps_in the projection has been applied already (conv_chain.hip's tail chain): elementwise only.
 __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
     __shared__ float w[4][64];
     __shared__ float bb[4];
     const int tid = threadIdx.x;
-    w[tid >> 6][tid & 63] = a.w[tid];
-    if (tid < 4) bb[tid] = a.b[tid];
-    __syncthreads();
+    if (!a.eps_in) {
+        w[tid >> 6][tid & 63] = a.w[tid];
+        if (tid < 4) bb[tid] = a.b[tid];
+        __syncthreads();
+    }
     const int row = blockIdx.x * 256 + tid;
     if (row >= a.b_pad * 52) return;
+    const bool real = row < a.B * 52;
+    v4f eps;
+    if (a.eps_in) {
+        eps = reinterpret_cast<const v4f*>(a.eps_in)[row];
+        if (a.eps_in_uncond) {
+            const v4f u = reinterpret_cast<const v4f*>(a.eps_in_uncond)[row];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) eps[d] = (1.0f + a.cfg_w) * eps[d] - a.cfg_w * u[d];
+        }
+    } else {
     const v4f* f4 = reinterpret_cast<const v4f*>(a.f + (size_t)row * 64);
     float e[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -204,8 +217,6 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
             e[d] = fmaf(f[3], w[d][4 * k4 + 3], e[d]);
         }
     }
-    const bool real = row < a.B * 52;
-    v4f eps;
 #pragma unroll
     for (int d = 0; d < 4; ++d) eps[d] = e[d] + bb[d];
     if (a.f_uncond) {   // classifier-free guidance in noise space (upstream diffuser.py:787)
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d) eps[d] = (1.0f + a.cfg_w) * eps[d] - a.cfg_w * (u[d] + bb[d]);
+    }
     }
     if (a.eps_out && real) reinterpret_cast<v4f*>(a.eps_out)[row] = eps;
     if (!a.mean_out && !a.x_out) return;

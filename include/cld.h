@@ -358,16 +358,20 @@ int cld_debug_guide_stamps(void* out /*HOST, u64[2048]*/);
  * workgroups of which stream can share a CU when two handles run on two streams (scripts/exp_streams.py). */
 int cld_debug_lds_floor(cld_handle h, size_t bytes);
 
-/* Tests only: force the formulation of one of the three recurrent kernels of this handle instead of letting the batch size
+/* Tests only: force the formulation of one of the three recurrent kernels (or of the U-Net's layer chains) of this handle instead of letting the batch size
  * pick it (all forms compute the same function; the parity tests run each against the oracle).  The shipped library reads
  * no environment variable: every behaviour switch is an explicit call like this one. */
 #define CLD_KERNEL_GUIDE 0    /* guidance: LSTM forward + BPTT + roll-out backward (cld_sample_guided, cld_guidance_step) */
 #define CLD_KERNEL_DECODE 1   /* cld_lstm_decode, cld_decode */
 #define CLD_KERNEL_ENCODE 2   /* cld_traj2z */
+#define CLD_KERNEL_UNET 3     /* the 64-channel levels of a U-Net evaluation: CLD_FORM_AUTO by batch size, CLD_FORM_LAYERS one launch
+                               * per layer (conv_block.hip), CLD_FORM_CHAIN the LDS-resident layer chains (conv_chain.hip) */
 #define CLD_FORM_AUTO 0       /* by batch size (default) */
 #define CLD_FORM_VALU 1       /* one or two agents per workgroup, gate rows in registers */
 #define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 16x16x4 MFMA tiles */
 #define CLD_FORM_MFMA_QUAD 3  /* guide only: 8 agents per workgroup on the 16-block 4x4x1 fp32 MFMA (the form 2,048 agents run in) */
+#define CLD_FORM_LAYERS 1     /* CLD_KERNEL_UNET only */
+#define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);
 
 /* CLD_PRECISION_* the handle runs with. */
