@@ -30,6 +30,7 @@ namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 #ifdef CLD_STAMPS
 // diagnostic build: in-kernel cycle stamps (never compiled into the shipped library)
@@ -122,49 +123,64 @@ __device__ __forceinline__ void kloop(v4f (&acc)[NMT], const char* ldsb, const i
     }
 }
 
-// sum over the 8 lanes of a GroupNorm group (channels) and the 4 lane groups (rows) that hold one agent's values
+// sum over the 8 lanes of a GroupNorm group (channels) and the 4 lane groups (rows) that hold one agent's values, left in every
+// lane: three DPP adds inside the 16-lane row (after the two quad steps every lane of a quad holds the quad's sum, so the
+// half-row mirror is as good as an xor by 4) and the gfx950 row / half swaps -- pure VALU, no LDS crossbar
+#define CLD_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
 __device__ __forceinline__ float group_sum(float s) {
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    return s;
+    s += CLD_DPP(s, 0xB1);       // quad_perm:[1,0,3,2]
+    s += CLD_DPP(s, 0x4E);       // quad_perm:[2,3,0,1]
+    s += CLD_DPP(s, 0x141);      // row_half_mirror
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+    const unsigned a16 = r16[0], b16 = r16[1];      // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0)
+    s = __builtin_bit_cast(float, a16) + __builtin_bit_cast(float, b16);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+    const unsigned a32 = r32[0], b32 = r32[1];
+    return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);
 }
 
 // GroupNorm(8 channels x L rows per agent, eps 1e-5, biased variance; diffuser_helpers.py:61) + Mish + per-agent vector, on the
-// accumulators of one wave: lane (n, q) register r of M-tile m = (agent r, row RPT m + q, channel 16 wave + n).
+// accumulators of one wave: lane (n, q) register r of M-tile m = (agent r, row RPT m + q, channel 16 wave + n).  Written on
+// register PAIRS (agents 0 | 1 and 2 | 3) so that the adds / multiplies / FMAs compile to the packed fp32 instructions
+// (v_pk_add_f32, v_pk_mul_f32, v_pk_fma_f32: two values per issue slot) -- the epilogue is issue-bound next to the other
+// workgroup's MFMA loop, and only the exponential, the reciprocal and the clamp stay one value per instruction.
 template <class G>
 __device__ __forceinline__ void gn_mish(v4f (&acc)[G::NMT], const float bias, const float gam, const float bet, const float (&add)[4], const int q) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const v2f bias2 = {bias, bias};
+    v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < G::NMT; ++m) {
-        const bool ok = !G::RAGGED || m < G::NMT - 1 || G::RPT * m + q < G::L;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[m][r] += bias;
-            s[r] += ok ? acc[m][r] : 0.f;
-        }
+        v2f lo = v2f{acc[m][0], acc[m][1]} + bias2, hi = v2f{acc[m][2], acc[m][3]} + bias2;
+        acc[m] = v4f{lo[0], lo[1], hi[0], hi[1]};
+        if (G::RAGGED && m == G::NMT - 1 && G::RPT * m + q >= G::L) { lo = v2f{0.f, 0.f}; hi = v2f{0.f, 0.f}; }
+        s01 += lo; s23 += hi;
     }
-    float mean[4], sc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) mean[r] = group_sum(s[r]) * (1.0f / (float)(8 * G::L));
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    const float inv = 1.0f / (float)(8 * G::L);
+    const v2f mean01 = {group_sum(s01[0]) * inv, group_sum(s01[1]) * inv}, mean23 = {group_sum(s23[0]) * inv, group_sum(s23[1]) * inv};
+    v2f q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < G::NMT; ++m) {
-        const bool ok = !G::RAGGED || m < G::NMT - 1 || G::RPT * m + q < G::L;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = acc[m][r] - mean[r];
-            ss[r] += ok ? d * d : 0.f;
-        }
+        v2f lo = v2f{acc[m][0], acc[m][1]} - mean01, hi = v2f{acc[m][2], acc[m][3]} - mean23;
+        if (G::RAGGED && m == G::NMT - 1 && G::RPT * m + q >= G::L) { lo = v2f{0.f, 0.f}; hi = v2f{0.f, 0.f}; }
+        q01 += lo * lo; q23 += hi * hi;
     }
+    const v2f sc01 = {(1.0f / sqrtf(group_sum(q01[0]) * inv + 1e-5f)) * gam, (1.0f / sqrtf(group_sum(q01[1]) * inv + 1e-5f)) * gam};
+    const v2f sc23 = {(1.0f / sqrtf(group_sum(q23[0]) * inv + 1e-5f)) * gam, (1.0f / sqrtf(group_sum(q23[1]) * inv + 1e-5f)) * gam};
+    const v2f bet2 = {bet, bet}, add01 = {add[0], add[1]}, add23 = {add[2], add[3]}, two = {2.0f, 2.0f};
+    auto mish2 = [&](const v2f x, const v2f ad) {          // x n / (n + 2) + ad, n = e^x (e^x + 2)   (conv_block.hip mish_f)
+        const v2f c = v2f{fminf(x[0], 30.0f), fminf(x[1], 30.0f)} * v2f{1.4426950408889634f, 1.4426950408889634f};
+        const v2f e = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
+        const v2f nn = e * (e + two);
+        const v2f d = nn + two;
+        const v2f r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return (x * nn) * r + ad;
+    };
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[r] = (1.0f / sqrtf(group_sum(ss[r]) * (1.0f / (float)(8 * G::L)) + 1e-5f)) * gam;
-#pragma unroll
-    for (int m = 0; m < G::NMT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[m][r] = mish_c((acc[m][r] - mean[r]) * sc[r] + bet) + add[r];
+    for (int m = 0; m < G::NMT; ++m) {
+        const v2f lo = mish2((v2f{acc[m][0], acc[m][1]} - mean01) * sc01 + bet2, add01);
+        const v2f hi = mish2((v2f{acc[m][2], acc[m][3]} - mean23) * sc23 + bet2, add23);
+        acc[m] = v4f{lo[0], lo[1], hi[0], hi[1]};
+    }
 }
 
 // accumulators -> the image rows of the next layer (every lane one float per (M-tile, agent): 64-byte runs per lane group)
@@ -278,7 +294,9 @@ __global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const v4f x4 = *reinterpret_cast<const v4f*>(xl + (r * 52 + 4 * m + q) * 4);
-                    acc[m][r] += b4 + w4[0] * x4[0] + w4[1] * x4[1] + w4[2] * x4[2] + w4[3] * x4[3];
+                    // explicit FMAs: whatever the vectoriser does with the four agents of a register quad, every element
+                    // sees the same operation sequence (a row's result must not depend on its place in the tile)
+                    acc[m][r] += fmaf(w4[3], x4[3], fmaf(w4[2], x4[2], fmaf(w4[1], x4[1], fmaf(w4[0], x4[0], b4))));
                 }
         } else if (st.res_kind == CHAIN_RES_KEPT) {
 #pragma unroll
