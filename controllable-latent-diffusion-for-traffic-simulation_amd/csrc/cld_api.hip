@@ -56,7 +56,7 @@ struct cld_handle_s {
     bool finalized = false, has_decoder = false, has_unet = false;
     std::vector<void*> dev_allocs;
     // schedule (host, fp32 as in dm_model.py:29-56)
-    std::vector<float> x_t_cof, noise_cof, plvc, sqrt_acp, sqrt_1m_acp;
+    std::vector<float> x_t_cof, noise_cof, plvc, sqrt_acp, sqrt_1m_acp, sqrt_recip_acp, sqrt_recipm1_acp;
     float* qs_tab = nullptr;            // device [2][n_timesteps]: sqrt(alphas_cumprod), sqrt(1 - alphas_cumprod) (q_sample, dm_model.py:91-96)
     // device-side model
     ResBlock blocks[12];
@@ -207,9 +207,12 @@ void build_schedule(cld_handle h) {
     double run = 1.0;
     for (int i = 0; i < n; ++i) { run *= (double)alphas[i]; acp[i] = (float)run; acp_prev[i] = i ? acp[i - 1] : 1.0f; }
     h->x_t_cof.resize(n); h->noise_cof.resize(n); h->plvc.resize(n); h->sqrt_acp.resize(n); h->sqrt_1m_acp.resize(n);
+    h->sqrt_recip_acp.resize(n); h->sqrt_recipm1_acp.resize(n);
     for (int i = 0; i < n; ++i) {
         h->sqrt_acp[i] = std::sqrt(acp[i]);                 // dm_model.py:36-37
         h->sqrt_1m_acp[i] = std::sqrt(1.0f - acp[i]);
+        h->sqrt_recip_acp[i] = std::sqrt(1.0f / acp[i]);             // dm_model.py:40-41 (registered there, read by upstream's predict_start_from_noise)
+        h->sqrt_recipm1_acp[i] = std::sqrt(1.0f / acp[i] - 1.0f);
         const float pv = betas[i] * (1.0f - acp_prev[i]) / (1.0f - acp[i]);
         h->plvc[i] = (float)std::log((double)(pv < 1e-20f ? 1e-20f : pv));      // correctly rounded: equals torch.log on every entry of the n = 10 / 50 / 100 tables
         h->x_t_cof[i] = std::sqrt(1.0f / alphas[i]);
@@ -358,8 +361,12 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
 
 struct Ws {
     float *xw, *xtmp, *meanb, *cb, *buf[NBUF], *guide;
+    float *gcur, *adam_m, *adam_v;      // multi-step guidance: current iterate and Adam moments [b_pad,52,4] each
+    float *col_traj, *col_grad;         // collision term: decoded plans and d total / d plans [b_pad,52,6] each
 };
-size_t ws_floats(int b_pad) { return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT) + guide_scratch_floats(b_pad); }
+size_t ws_floats(int b_pad) {
+    return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT) + guide_scratch_floats(b_pad) + (size_t)b_pad * (3 * T * D + 2 * T * 6);
+}
 Ws carve(void* ws, int b_pad) {
     Ws w;
     float* p = static_cast<float*>(ws);
@@ -368,7 +375,12 @@ Ws carve(void* ws, int b_pad) {
     w.meanb = p; p += (size_t)b_pad * T * D;
     w.cb = p; p += (size_t)b_pad * NCB;
     for (int i = 0; i < NBUF; ++i) { w.buf[i] = p; p += (size_t)b_pad * ACT; }
-    w.guide = p;       // activations kept by the guidance kernel's LSTM forward (guide_scratch_floats)
+    w.guide = p; p += guide_scratch_floats(b_pad);      // activations kept by the guidance kernel's LSTM forward
+    w.gcur = p; p += (size_t)b_pad * T * D;
+    w.adam_m = p; p += (size_t)b_pad * T * D;
+    w.adam_v = p; p += (size_t)b_pad * T * D;
+    w.col_traj = p; p += (size_t)b_pad * T * 6;
+    w.col_grad = p;
     return w;
 }
 inline int pad16(int b) { return (b + 15) / 16 * 16; }
@@ -1161,14 +1173,75 @@ int cld_ddpm_step(cld_handle h, const float* x, const float* cond, int32_t t_idx
     return CLD_OK;
 }
 
-static int check_guidance(cld_handle h, const char* fn, const cld_guidance* gd) {
+static int check_collision(cld_handle h, const char* fn, const cld_collision* c, int B) {
+    if (!c->extent || !c->world_from_agent || !c->curr_speed || !c->scene_start) return fail(h, CLD_ERR_ARG, std::string(fn) + ": collision term: null pointer");
+    if (c->num_scenes < 1 || c->num_samp < 1 || B % c->num_samp) return fail(h, CLD_ERR_ARG, std::string(fn) + ": collision term: B must be agents x num_samp, num_scenes >= 1");
+    if (c->num_disks < 1 || c->num_disks > 8) return fail(h, CLD_ERR_ARG, std::string(fn) + ": collision term: num_disks must be 1..8");
+    if (c->max_scene_agents < 1 || c->max_scene_agents > 150) return fail(h, CLD_ERR_ARG, std::string(fn) + ": collision term: scenes of 1..150 agents");
+    return CLD_OK;
+}
+
+static int check_guidance(cld_handle h, const char* fn, const cld_guidance* gd, int B) {
     if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
-    if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad))
+    if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad && !gd->collision))
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
+    if (gd->collision) {
+        const int rcc = check_collision(h, fn, gd->collision, B);
+        if (rcc) return rcc;
+    }
+    if (gd->grad_steps < 0 || gd->final_grad_steps < 0 || gd->grad_steps > 64 || gd->final_grad_steps > 64)
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": grad_steps out of range (0..64)");
     if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer");
     if (gd->apply_output && gd->final_optimizer != CLD_GUIDE_ADAM && gd->final_optimizer != CLD_GUIDE_SGD)
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": unknown optimizer for the output step");
     if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, std::string(fn) + ": target_pos_scale needs target_pos and target_time");
+    return CLD_OK;
+}
+
+// The guidance step(s) of one denoising iteration on the posterior mean `mean0` (upstream perturb(), guidance_loss.py:2221-2282):
+// grad_steps optimiser steps, each one guidance-kernel launch (decoder forward + roll-out + loss gradients + BPTT + update) on the
+// current iterate; with a collision term each step first decodes the iterate and runs the AgentCollisionLoss kernel, whose
+// gradient w.r.t. the plans enters the guidance kernel as ext_grad.  The last step adds sigma z and writes x_out (/ x_out2).
+// `intermediate`: a t > 0 step (lr / perturb_th / optimizer / grad_steps) or the output step (final_*).
+static int run_guidance(cld_handle h, const Ws& w, const cld_guidance* gd, int B, bool intermediate, float sigma_t, float sigma_noise,
+                        const float* mean0, const float* cond, const float* z, uint64_t seed, unsigned long long salt,
+                        float* mean_out, float* x_out, float* x_out2, float* grad_out, hipStream_t s) {
+    GuideArgs g{};
+    g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed; g.loss_scale = gd->loss_scale;
+    g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
+    g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
+    g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
+    g.ext_grad = gd->ext_grad;
+    // t = 0 (apply_guidance_output): the step's own optimiser settings, and no noise behind it (nonzero_mask, diffuser.py:929)
+    const float lr_in = intermediate ? gd->lr : gd->final_lr, th_in = intermediate ? gd->perturb_th : gd->final_perturb_th;
+    g.scratch = w.guide; g.lr = lr_in > 0.f ? lr_in : sigma_t; g.perturb_th = th_in > 0.f ? th_in : (th_in == 0.f ? sigma_t : -1.f);
+    g.optimizer = intermediate ? gd->optimizer : gd->final_optimizer; g.B = B; g.seed = seed; g.step_salt = salt;
+    const int steps_in = intermediate ? gd->grad_steps : gd->final_grad_steps;
+    const int steps = steps_in > 1 ? steps_in : 1;
+    g.opt_steps = steps; g.mean0 = mean0; g.adam_m = w.adam_m; g.adam_v = w.adam_v;
+    for (int k = 1; k <= steps; ++k) {
+        const bool last = k == steps;
+        g.opt_step = k;
+        g.mean = k == 1 ? mean0 : w.gcur;
+        if (gd->collision) {
+            const cld_collision* c = gd->collision;
+            HIPCK(h, launch_decode(h->dec, h->dyn, g.mean, cond, gd->curr_states, nullptr, w.col_traj, B, 1, s, h->force_kernel[CLD_KERNEL_DECODE]));
+            CollisionArgs ca{};
+            ca.traj = w.col_traj; ca.extent = c->extent; ca.world_from_agent = c->world_from_agent; ca.curr_speed = c->curr_speed;
+            ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.grad_in = gd->ext_grad;
+            ca.grad = w.col_grad; ca.B_agents = B / c->num_samp; ca.num_scenes = c->num_scenes; ca.num_samp = c->num_samp;
+            ca.num_disks = c->num_disks; ca.buffer_dist = c->buffer_dist; ca.decay_rate = c->decay_rate; ca.moving_speed_th = c->moving_speed_th;
+            HIPCK(h, launch_agent_collision(ca, c->max_scene_agents, s));
+            g.ext_grad = w.col_grad;
+        }
+        g.z = last ? z : nullptr;
+        g.sigma = last ? sigma_noise : 0.f;
+        g.mean_out = last ? mean_out : w.gcur;           // in place from step 2 on: a workgroup reads its agents' rows before it writes them
+        g.x_out = last ? x_out : nullptr;
+        g.x_out2 = last ? x_out2 : nullptr;
+        g.grad_out = k == 1 ? grad_out : nullptr;        // dL/dmean of the FIRST step (what the single-step call reports)
+        HIPCK(h, launch_guide(h->dec, h->dyn, g, s, h->force_kernel[CLD_KERNEL_GUIDE]));
+    }
     return CLD_OK;
 }
 
@@ -1199,6 +1272,9 @@ static int sample_iteration(cld_handle h, const Ws& w, bool cfg, int B, int bp, 
     a.sg = (i == 0) ? 0.f : sigma;           // nonzero_mask, dm_model.py:151
     if (guide) {
         a.mean_out = w.meanb;                            // the guidance kernel perturbs the mean and adds the noise
+        if (gd->guide_clean) {                           // ... or the model's clean prediction x0_hat (diffuser.py:866-873, :710-719)
+            a.xc = h->sqrt_recip_acp[i]; a.nc = h->sqrt_recipm1_acp[i];
+        }
     } else {
         a.x_out = w.xw;                                  // in place: each thread rewrites the row it read
         a.x_out2 = cfg ? x_hi : nullptr;
@@ -1206,21 +1282,11 @@ static int sample_iteration(cld_handle h, const Ws& w, bool cfg, int B, int bp, 
     }
     HIPCK(h, launch_head(a, s));
     if (guide) {
-        GuideArgs g{};
-        g.mean = w.meanb; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed;
-        g.loss_scale = gd->loss_scale; g.z = a.z; g.x_out = w.xw; g.x_out2 = cfg ? x_hi : nullptr;
         // a guided t = 0 step (apply_output): x0 IS the guided mean, and log_prob_final is taken around it (w.xtmp), not around the
         // unguided mean it was stepped away from -- sigma_0 = 1e-10 would turn that step into ~ -1e18
-        g.mean_out = mean_guided ? mean_guided : (i == 0 ? w.xtmp : nullptr); g.grad_out = grad;
-        g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
-        g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
-        g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
-        g.ext_grad = gd->ext_grad;
-        // t = 0 (apply_guidance_output): the step's own optimiser settings, and no noise behind it (nonzero_mask, diffuser.py:929)
-        const float lr_in = i > 0 ? gd->lr : gd->final_lr, th_in = i > 0 ? gd->perturb_th : gd->final_perturb_th;
-        g.scratch = w.guide; g.lr = lr_in > 0.f ? lr_in : sigma; g.perturb_th = th_in > 0.f ? th_in : (th_in == 0.f ? sigma : -1.f);
-        g.sigma = a.sg; g.optimizer = i > 0 ? gd->optimizer : gd->final_optimizer; g.B = B; g.seed = seed; g.step_salt = salt;
-        HIPCK(h, launch_guide(h->dec, h->dyn, g, s, h->force_kernel[CLD_KERNEL_GUIDE]));
+        int rcg = run_guidance(h, w, gd, B, i > 0, sigma, a.sg, w.meanb, cond, a.z, seed, salt, mean_guided ? mean_guided : (i == 0 ? w.xtmp : nullptr),
+                               w.xw, cfg ? x_hi : nullptr, grad, s);
+        if (rcg) return rcg;
     }
     return CLD_OK;
 }
@@ -1234,7 +1300,7 @@ static int sample_impl(cld_handle h, const char* fn, const float* x_T, const flo
     if (!x_T || !cond) return fail(h, CLD_ERR_ARG, std::string(fn) + ": null pointer");
     if (steps != loop_steps(h))
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": steps must equal len(range(0, n_timesteps, stride)) = " + std::to_string(loop_steps(h)));
-    if (gd && (rc = check_guidance(h, fn, gd)) != CLD_OK) return rc;
+    if (gd && (rc = check_guidance(h, fn, gd, B)) != CLD_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // CFG: one 2B-agent batch per step: rows [0, bp) carry cond_feat, rows [bp, 2bp) the unconditional features,
     // both halves the same latent; the head combines the two noise predictions and rewrites both halves.
@@ -1268,7 +1334,7 @@ int cld_sample_step(cld_handle h, const float* x_t, const float* cond, const flo
     int rc = check_common(h, "cld_sample_step", cfg ? 2 * pad16(B) : B, t_idx, workspace, workspace_bytes);
     if (rc) return rc;
     if (!x_t || !cond || (!z && t_idx != 0)) return fail(h, CLD_ERR_ARG, "cld_sample_step: null pointer");
-    if (gd && (rc = check_guidance(h, "cld_sample_step", gd)) != CLD_OK) return rc;
+    if (gd && (rc = check_guidance(h, "cld_sample_step", gd, B)) != CLD_OK) return rc;
     if (sigma_host) *sigma_host = std::exp(0.5f * h->plvc[t_idx]);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int bp = pad16(B), bpn = cfg ? 2 * bp : bp;
@@ -1314,23 +1380,10 @@ int cld_guidance_step(cld_handle h, const float* mean, const float* cond, const 
     int rc = check_common(h, "cld_guidance_step", B, 0, workspace, workspace_bytes);
     if (rc) return rc;
     if (!h->has_decoder) return fail(h, CLD_ERR_STATE, "cld_guidance_step: decoder weights not loaded");
-    if (!mean || !cond || !gd || !gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad) ||
-        (x_next && sigma != 0.f && !z))
-        return fail(h, CLD_ERR_ARG, "cld_guidance_step: null pointer");
-    if (gd->optimizer != CLD_GUIDE_ADAM && gd->optimizer != CLD_GUIDE_SGD) return fail(h, CLD_ERR_ARG, "cld_guidance_step: unknown optimizer");
-    if (gd->target_pos_scale && (!gd->target_pos || !gd->target_time)) return fail(h, CLD_ERR_ARG, "cld_guidance_step: target_pos_scale needs target_pos and target_time");
+    if (!mean || !cond || !gd || (x_next && sigma != 0.f && !z)) return fail(h, CLD_ERR_ARG, "cld_guidance_step: null pointer");
+    if ((rc = check_guidance(h, "cld_guidance_step", gd, B)) != CLD_OK) return rc;
     Ws w = carve(workspace, pad16(B));
-    GuideArgs g{};
-    g.mean = mean; g.cond = cond; g.curr_states = gd->curr_states; g.target_speed = gd->target_speed; g.loss_scale = gd->loss_scale;
-    g.speed_limit_scale = gd->speed_limit_scale; g.acc_limit_scale = gd->acc_limit_scale;
-    g.speed_limit = gd->speed_limit; g.acc_limit = gd->acc_limit;
-    g.target_pos = gd->target_pos; g.target_time = gd->target_time; g.target_pos_scale = gd->target_pos_scale;
-    g.ext_grad = gd->ext_grad;
-    g.z = z; g.mean_out = mean_guided; g.x_out = x_next; g.grad_out = grad; g.scratch = w.guide;
-    g.lr = gd->lr > 0.f ? gd->lr : sigma; g.perturb_th = gd->perturb_th > 0.f ? gd->perturb_th : (gd->perturb_th == 0.f ? sigma : -1.f);
-    g.sigma = sigma; g.optimizer = gd->optimizer; g.B = B;
-    HIPCK(h, launch_guide(h->dec, h->dyn, g, static_cast<hipStream_t>(stream), h->force_kernel[CLD_KERNEL_GUIDE]));
-    return CLD_OK;
+    return run_guidance(h, w, gd, B, true, sigma, sigma, mean, cond, z, 0, 0, mean_guided, x_next, nullptr, grad, static_cast<hipStream_t>(stream));
 }
 
 int cld_guidance_losses(cld_handle h, const float* traj, const cld_guidance* gd, float* losses, int32_t B, void* stream) {
@@ -1501,6 +1554,21 @@ int cld_compute_reward(cld_handle h, const float* traj, const float* traj_scaled
     a.other_pos = other_pos; a.other_avail = other_avail; a.reward = reward; a.offroad = offroad; a.collision = collision;
     a.collision_thresh = collision_thresh; a.B = B; a.H = H; a.W = W; a.S = S; a.To = T_other < T ? T_other : T;
     HIPCK(h, launch_reward(a, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+int cld_agent_collision(cld_handle h, const float* traj, const cld_collision* c, const float* grad_in, float* loss, float* grad,
+                        int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!traj || !c || B < 1 || (!loss && !grad)) return fail(h, CLD_ERR_ARG, "cld_agent_collision: bad argument");
+    int rc = check_collision(h, "cld_agent_collision", c, B);
+    if (rc) return rc;
+    CollisionArgs ca{};
+    ca.traj = traj; ca.extent = c->extent; ca.world_from_agent = c->world_from_agent; ca.curr_speed = c->curr_speed;
+    ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.grad_in = grad_in;
+    ca.loss = loss; ca.grad = grad; ca.B_agents = B / c->num_samp; ca.num_scenes = c->num_scenes; ca.num_samp = c->num_samp;
+    ca.num_disks = c->num_disks; ca.buffer_dist = c->buffer_dist; ca.decay_rate = c->decay_rate; ca.moving_speed_th = c->moving_speed_th;
+    HIPCK(h, launch_agent_collision(ca, c->max_scene_agents, static_cast<hipStream_t>(stream)));
     return CLD_OK;
 }
 

@@ -252,7 +252,14 @@ struct GuideArgs {
     float* grad_out;            // dL/dmean [B,52,4] or null (diagnostic / tests)
     float* scratch;             // guide_scratch_floats(B) floats
     float lr, perturb_th, sigma;
-    int optimizer;              // 0 = Adam (first step), 1 = SGD
+    int optimizer;              // 0 = Adam, 1 = SGD
+    // optimiser steps beyond the first (upstream grad_steps > 1: one torch.optim.Adam / SGD per perturb() call, its state carried
+    // across the steps): step opt_step (1-based) of opt_steps; `mean` is then the CURRENT iterate, mean0 the posterior mean the
+    // clip is taken around (null: mean), adam_m / adam_v [B,52,4] the moments (read when opt_step > 1, written when more steps follow)
+    int opt_step, opt_steps;
+    const float* mean0;
+    float* adam_m;
+    float* adam_v;
     int B;
     unsigned long long seed, step_salt;
 };
@@ -263,6 +270,23 @@ hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const Guide
 // per-agent values of the built-in guidance losses on a decoded trajectory (include/cld.h cld_guidance_losses); uses the loss
 // fields of GuideArgs (target_speed, loss_scale, speed/acc limits, waypoint) and B
 hipError_t launch_guide_losses(const GuideArgs& a, const float* traj, float* losses, hipStream_t s);
+
+// upstream's AgentCollisionLoss + its gradient w.r.t. the decoded plans (collision_kernels.hip; guidance_loss.py:442-630)
+struct CollisionArgs {
+    const float* traj;              // [B_agents * num_samp, 52, 6] descaled plans, sample-minor
+    const float* extent;            // [B_agents, 3] length, width, height
+    const float* world_from_agent;  // [B_agents, 3, 3]
+    const float* curr_speed;        // [B_agents]
+    const int* scene_start;         // [num_scenes + 1] agent offsets of the scenes
+    const float* scene_weight;      // [num_scenes] weight of the scene's agent_collision config (0: not guided) or null (1 everywhere)
+    const unsigned char* guided;    // [B_agents] or null: the config's `agents` subset
+    const float* grad_in;           // [B_agents * num_samp, 52, 6] or null: added to the output gradient
+    float* loss;                    // [B_agents * num_samp] per-agent values (unweighted, as upstream files them) or null
+    float* grad;                    // [B_agents * num_samp, 52, 6] d total / d traj, or null
+    int B_agents, num_scenes, num_samp, num_disks;
+    float buffer_dist, decay_rate, moving_speed_th;
+};
+hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, hipStream_t s);
 
 // PPO reward (models/rl/criticmodel.py:7-64)
 struct RewardArgs {

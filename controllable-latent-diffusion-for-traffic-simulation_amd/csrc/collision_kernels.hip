@@ -1,0 +1,160 @@
+// collision_kernels.hip -- upstream's AgentCollisionLoss (src/tbsim/utils/guidance_loss.py:442-630) and its gradient w.r.t. the
+// decoded plans, as one launch: the scene-coupled guidance loss of "controllable" traffic simulation, which the round-2 library
+// left to caller torch code (a host round trip per denoising step).
+//
+// Upstream builds, for every (sample, step), the B x B x 25 table of disk-centre distances of ALL agent pairs of the batch and
+// masks it down to the pairs of one scene.  Here a workgroup owns one (scene, sample): the world poses of the scene's agents at
+// all 52 steps sit in LDS (16 B per pose), one thread per (agent, step) walks the other agents of ITS scene only, rejects far
+// pairs on the centre distance (exact: a disk centre lies within length / 2 - radius of the agent's centre), and evaluates the
+// 25 disk pairs of the rest.  The value and the gradient come out of the same pass: the loss is
+//     value[i] = [moving_i] sum_t w_t (1 / B) sum_j pen_ij(t),  pen = 1 - d_ij / (r_i + r_j + buffer)  where d_ij <= that bound,
+//     total    = sum_scenes weight_s * mean over the scene's guided agents (and samples) of value   (DiffuserGuidance, :2143-2172),
+// pen is symmetric in (i, j), agents that are stationary or not guided are detached (:512-534), so
+//     d total / d pose_i = [i guided and moving] * weight_s / (M_s N B) * sum_t w_t sum_j (1 + [j guided and moving]) d pen_ij / d pose_i.
+// Output grad [B N, 52, 6] is dL/d(descaled trajectory) -- the `ext_grad` operand of the guidance kernels (guide_kernels.hip),
+// which turn it into dL/d(latent) through roll-out and decoder.
+#include "cld_kernels.h"
+
+namespace cld {
+
+namespace {
+constexpr int TT = 52;
+constexpr int kMaxDisks = 8;
+
+// torch.linspace(-e, e, D)[a] as ATen computes it: from the start below the midpoint, from the end above it (init_disks, :481-492)
+__device__ __forceinline__ float disk_centre(float e, int a, int D) {
+    if (D <= 1) return -e;
+    const float step = (e - (-e)) / (float)(D - 1);
+    return a < D / 2 ? -e + step * (float)a : e - step * (float)(D - 1 - a);
+}
+
+__global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.x / p.num_samp, n = blockIdx.x % p.num_samp;
+    const int a0 = p.scene_start[s], A = p.scene_start[s + 1] - a0;
+    const int tid = threadIdx.x;
+    float4* pose = reinterpret_cast<float4*>(lds);                 // [A][52]: world x, y, cos / sin of the world heading
+    float* part = lds + (size_t)A * TT * 4;                        // [A][52]: sum_j pen_ij(t) (weighted) -> per-agent values
+    float* agent = part + (size_t)A * TT;                          // [A][4]: radius, half extent of the disk centres, row-active flag, unused
+    int& n_guided = *reinterpret_cast<int*>(agent + (size_t)A * 4);   // (in the dynamic allocation: a static __shared__ next to a 160-KB dynamic request is refused)
+    const float wgt = p.scene_weight ? p.scene_weight[s] : 1.0f;
+
+    if (tid == 0) n_guided = 0;
+    __syncthreads();
+    for (int i = tid; i < A; i += 256) {
+        const int b = a0 + i;
+        const float len = p.extent[b * 3 + 0], wid = p.extent[b * 3 + 1];
+        const float rad = wid * 0.5f;
+        const bool guided = wgt != 0.f && (!p.guided || p.guided[b]);
+        const bool moving = fabsf(p.curr_speed[b]) > p.moving_speed_th;
+        agent[i * 4 + 0] = rad;
+        agent[i * 4 + 1] = len * 0.5f - rad;                       // disk centres run from -this to +this along the agent's axis (:481-492)
+        agent[i * 4 + 2] = (guided && moving) ? 1.f : 0.f;
+        agent[i * 4 + 3] = moving ? 1.f : 0.f;
+        if (guided) atomicAdd(&n_guided, 1);
+    }
+    // world poses (geometry_utils.py:458-483): p_w = R p + t; heading = atan2 of the rotated unit vector
+    for (int it = tid; it < A * TT; it += 256) {
+        const int i = it / TT, t = it - i * TT, b = a0 + i;
+        const float* W = p.world_from_agent + (size_t)b * 9;
+        const float* x = p.traj + ((size_t)(b * p.num_samp + n) * TT + t) * 6;
+        float sy, cy;
+        sincosf(x[3], &sy, &cy);
+        const float hx = W[0] * cy + W[1] * sy, hy = W[3] * cy + W[4] * sy;
+        const float yw = atan2f(hy, hx);
+        float sw, cw;
+        sincosf(yw, &sw, &cw);
+        pose[it] = make_float4(W[0] * x[0] + W[1] * x[1] + W[2], W[3] * x[0] + W[4] * x[1] + W[5], cw, sw);
+    }
+    __syncthreads();
+
+    // normalised step weights decay^t / sum (:614-616)
+    float wsum = 0.f, wp = 1.f;
+    for (int t = 0; t < TT; ++t) { wsum += wp; wp *= p.decay_rate; }
+    const int D = p.num_disks;
+    const float inv_b = 1.0f / (float)p.B_agents;
+    const float coef = (n_guided > 0 && wgt != 0.f) ? wgt / ((float)n_guided * (float)p.num_samp * (float)p.B_agents) : 0.f;
+
+    for (int it = tid; it < A * TT; it += 256) {
+        const int i = it / TT, t = it - i * TT, b = a0 + i;
+        const float4 pi = pose[it];
+        const float ri = agent[i * 4 + 0], ei = agent[i * 4 + 1], acti = agent[i * 4 + 2];
+        const float wt = powf(p.decay_rate, (float)t) / wsum;
+        float cxi[kMaxDisks];
+#pragma unroll
+        for (int a = 0; a < kMaxDisks; ++a) cxi[a] = disk_centre(ei, a, D);
+        float pen_sum = 0.f, gx = 0.f, gy = 0.f, gyaw = 0.f;
+        for (int j = 0; j < A; ++j) {
+            if (j == i) continue;
+            const float4 pj = pose[j * TT + t];
+            const float rj = agent[j * 4 + 0], ej = agent[j * 4 + 1];
+            const float pd = ri + rj + p.buffer_dist;
+            const float dx = pi.x - pj.x, dy = pi.y - pj.y;
+            const float reach = pd + ei + ej + 1e-3f;
+            if (dx * dx + dy * dy > reach * reach) continue;       // no disk pair can be within pd
+            float best = 3.0e38f, bdx = 0.f, bdy = 0.f, bcx = 0.f;
+            for (int a = 0; a < D; ++a) {
+                const float ax = dx + cxi[a] * pi.z, ay = dy + cxi[a] * pi.w;
+                for (int c = 0; c < D; ++c) {
+                    const float cxj = disk_centre(ej, c, D);
+                    const float ex = ax - cxj * pj.z, ey = ay - cxj * pj.w;
+                    const float d2 = ex * ex + ey * ey;
+                    if (d2 < best) { best = d2; bdx = ex; bdy = ey; bcx = cxi[a]; }      // first minimum in (a, c) order, as torch.min
+                }
+            }
+            const float dist = sqrtf(best);
+            if (dist <= pd) {
+                pen_sum += 1.0f - dist / pd;
+                if (acti != 0.f && dist > 0.f) {
+                    // d pen / d c_i = -(c_i - c_j) / (dist pd); this pair is in row i's value and, when j's row counts, in row j's too
+                    const float k = -(1.0f + agent[j * 4 + 2]) / (dist * pd);
+                    const float gcx = k * bdx, gcy = k * bdy;
+                    gx += gcx; gy += gcy;
+                    gyaw += bcx * (-pi.w * gcx + pi.z * gcy);      // c_i = p_i + cx (cos, sin)(heading)
+                }
+            }
+        }
+        part[it] = pen_sum * wt * inv_b;
+        if (p.grad) {
+            float* g = p.grad + ((size_t)(b * p.num_samp + n) * TT + t) * 6;
+            const float* gi = p.grad_in ? p.grad_in + ((size_t)(b * p.num_samp + n) * TT + t) * 6 : nullptr;
+            const float sc = coef * wt * acti;
+            const float* W = p.world_from_agent + (size_t)b * 9;
+            // back through p_w = R p + t and heading = atan2(R (cos, sin)(yaw)): d heading / d yaw = (h x dh) / |h|^2
+            const float* x = p.traj + ((size_t)(b * p.num_samp + n) * TT + t) * 6;
+            float sy, cy;
+            sincosf(x[3], &sy, &cy);
+            const float hx = W[0] * cy + W[1] * sy, hy = W[3] * cy + W[4] * sy;
+            const float dhx = -W[0] * sy + W[1] * cy, dhy = -W[3] * sy + W[4] * cy;
+            const float dyaw = (hx * dhy - hy * dhx) / (hx * hx + hy * hy);
+            float o[6] = {sc * (W[0] * gx + W[3] * gy), sc * (W[1] * gx + W[4] * gy), 0.f, sc * gyaw * dyaw, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) g[k] = o[k] + (gi ? gi[k] : 0.f);
+        }
+    }
+    __syncthreads();
+    if (p.loss) {
+        for (int i = tid; i < A; i += 256) {
+            float v = 0.f;
+            for (int t = 0; t < TT; ++t) v += part[i * TT + t];    // fixed order: deterministic
+            p.loss[(size_t)(a0 + i) * p.num_samp + n] = agent[i * 4 + 3] != 0.f ? v : 0.f;
+        }
+    }
+}
+}  // namespace
+
+hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, hipStream_t s) {
+    if (a.num_disks < 1 || a.num_disks > kMaxDisks || a.num_scenes < 1 || a.num_samp < 1) return hipErrorInvalidValue;
+    const size_t lds_bytes = ((size_t)max_scene_agents * TT * 5 + (size_t)max_scene_agents * 4 + 4) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;          // a scene of more than ~150 agents: not built
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agent_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(agent_collision_kernel, dim3(a.num_scenes * a.num_samp), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace cld

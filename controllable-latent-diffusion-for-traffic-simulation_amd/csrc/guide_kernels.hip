@@ -433,6 +433,32 @@ __device__ __forceinline__ void mv64(float (&g)[GNA], const float* src, int off,
     }
 }
 
+// One optimiser step on one latent element (upstream perturb(), guidance_loss.py:2247-2278: torch.optim.Adam / SGD on x_guidance,
+// then the clip around x_initial).  Step 1 of Adam is -lr g / (|g| + eps) (bias-corrected moments of a single gradient); steps
+// k > 1 of a multi-step call carry torch's moments: m_k = 0.9 m + 0.1 g, v_k = 0.999 v + 0.001 g^2,
+// x -= (lr / (1 - 0.9^k)) m_k / (sqrt(v_k) / sqrt(1 - 0.999^k) + 1e-8).  SGD has no state.  `cur` is the current iterate.
+__device__ __forceinline__ float optimiser_step(const GuideArgs& a, float g, float cur, size_t gi) {
+    float delta;
+    if (a.optimizer != 0) {
+        delta = -a.lr * g;
+    } else if (a.opt_steps <= 1) {
+        delta = -a.lr * g / (fabsf(g) + 1e-8f);
+    } else {
+        float m = 0.1f * g, v = 0.001f * g * g;
+        if (a.opt_step > 1) { m = 0.9f * a.adam_m[gi] + m; v = 0.999f * a.adam_v[gi] + v; }
+        if (a.opt_step < a.opt_steps) { a.adam_m[gi] = m; a.adam_v[gi] = v; }
+        const float bc1 = 1.0f - powf(0.9f, (float)a.opt_step), bc2 = 1.0f - powf(0.999f, (float)a.opt_step);
+        delta = -(a.lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+    }
+    float mu = cur + delta;
+    if (a.perturb_th >= 0.f) {
+        const float m0 = a.mean0 ? a.mean0[gi] : cur;
+        mu = m0 + fminf(fmaxf(mu - m0, -a.perturb_th), a.perturb_th);
+    }
+    return mu;
+}
+
+
 __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, const DynParams d, const GuideArgs a) {
     constexpr int NA = GNA;
     __shared__ __attribute__((aligned(16))) float h0[NA][64], h1[NA][64], c0[NA][64], c1[NA][64], gates[NA][256], zin[NA][208];
@@ -661,9 +687,7 @@ __global__ __launch_bounds__(256) void guide_kernel(const DecoderWeights w, cons
             const int b = b0 + ag;
             if (b >= a.B || r >= 208) continue;
             const float g = dz[ag][r];
-            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;      // Adam's first step | SGD
-            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
-            const float mu = zin[ag][r] + delta;
+            const float mu = optimiser_step(a, g, zin[ag][r], (size_t)b * 208 + r);
             if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
             if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
             if (a.x_out) {
@@ -1067,9 +1091,7 @@ __global__ __launch_bounds__(512) void guide_mfma8_kernel(const DecoderWeights w
             const int ag = i / 208, r = i % 208, b = b0 + ag;
             if (b >= a.B) continue;
             const float g = dz[ag][r];
-            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
-            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
-            const float mu = zin[ag][r] + delta;
+            const float mu = optimiser_step(a, g, zin[ag][r], (size_t)b * 208 + r);
             if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
             if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
             if (a.x_out) {
@@ -1453,9 +1475,7 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
             const int ag = i / 208, r = i % 208, b = b0 + ag;
             if (b >= a.B) continue;
             const float g = dz[ag][r];
-            float delta = (a.optimizer == 0) ? -a.lr * g / (fabsf(g) + 1e-8f) : -a.lr * g;
-            if (a.perturb_th >= 0.f) delta = fminf(fmaxf(delta, -a.perturb_th), a.perturb_th);
-            const float mu = zin[ag][r] + delta;
+            const float mu = optimiser_step(a, g, zin[ag][r], (size_t)b * 208 + r);
             if (a.grad_out) a.grad_out[(size_t)b * 208 + r] = g;
             if (a.mean_out) a.mean_out[(size_t)b * 208 + r] = mu;
             if (a.x_out) {

@@ -214,7 +214,8 @@ class Engine:
 
     def _guidance(self, g: Mapping, B: int):
         """dict(curr_states [B,4], target_speed [B,52] | None, loss_scale [B] | None, speed_limit (limit, scale) | None,
-        acc_limit (limit, scale) | None, target_pos (pos [B,2], time index [B], scale) | None, lr | None, perturb_th | None | "sigma", optimizer "adam" | "sgd")
+        acc_limit (limit, scale) | None, target_pos (pos [B,2], time index [B], scale) | None, lr | None, perturb_th | None | "sigma", optimizer "adam" | "sgd",
+        grad_steps = 1, guide_clean = False, agent_collision: dict | None (see _collision))
         -> (CldGuidance, tensors kept alive).  A `scale` is a per-agent tensor [B] (weight / (agents of the scene * 52),
         as DiffuserGuidance averages) or a scalar weight (divided by 52 here).  lr None = sigma_t; perturb_th None = no clip (what
         the reference's perturb() does), "sigma" = clip to sigma_t, a number = clip to it (include/cld.h)."""
@@ -252,6 +253,9 @@ class Engine:
         if fopt not in _lib.OPTIMIZERS:
             raise CldError(f"unknown guidance optimizer '{fopt}' (adam | sgd)")
         fth = (fo or {}).get("perturb_th", None)       # None = no clip: what upstream's perturb() does (guidance_loss.py:2237,2273-2276)
+        col = ckeep = None
+        if g.get("agent_collision") is not None:
+            col, ckeep = self._collision(g["agent_collision"], B)
         cg = _lib.CldGuidance(cs.data_ptr(), None if ts is None else ts.data_ptr(), None if ls is None else ls.data_ptr(),
                               float(g["lr"]) if g.get("lr") else 0.0,
                               -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
@@ -260,8 +264,64 @@ class Engine:
                               None if tps is None else tps.data_ptr(), None if eg is None else eg.data_ptr(),
                               0 if fo is None or fo is False else 1, 0 if g.get("intermediate", True) else 1,
                               float((fo or {}).get("lr", 0.3) or 0.0),
-                              -1.0 if fth is None else (0.0 if fth == "sigma" else float(fth)), _lib.OPTIMIZERS[fopt])
-        return cg, (cs, ts, ls, sls, als, tp, tt, tps, eg)
+                              -1.0 if fth is None else (0.0 if fth == "sigma" else float(fth)), _lib.OPTIMIZERS[fopt],
+                              int(g.get("grad_steps", 1) or 1), int((fo or {}).get("grad_steps", 1) or 1), 1 if g.get("guide_clean") else 0,
+                              None if col is None else C.addressof(col))
+        return cg, (cs, ts, ls, sls, als, tp, tt, tps, eg, col, ckeep)
+
+    def _collision(self, c: Mapping, B: int):
+        """dict(extent [A,3], world_from_agent [A,3,3], curr_speed [A], scene_index [A] (consecutive blocks) | scene_sizes,
+        weight: scalar or per-scene sequence (0 = scene not guided), agents: optional {scene: local indices} (upstream's
+        `agents` of a guidance config), num_samp = 1, num_disks = 5, buffer_dist = 0.2, decay_rate = 0.9,
+        guide_moving_speed_th = 0.5) -> (CldCollision, tensors kept alive): upstream's AgentCollisionLoss
+        (src/tbsim/utils/guidance_loss.py:442-630) configured per scene as DiffuserGuidance does (:2106-2172).  B = A * num_samp."""
+        N = int(c.get("num_samp", 1))
+        if B % N:
+            raise CldError(f"agent_collision: {B} rows are not a multiple of num_samp = {N}")
+        A = B // N
+        ext = self._f32(c["extent"], (A, 3)); wfa = self._f32(c["world_from_agent"], (A, 3, 3)); spd = self._f32(c["curr_speed"], (A,))
+        if c.get("scene_sizes") is not None:
+            sizes = [int(v) for v in c["scene_sizes"]]
+        else:
+            si = torch.as_tensor(c["scene_index"]).cpu()
+            _, counts = torch.unique_consecutive(si, return_counts=True)
+            sizes = [int(v) for v in counts]
+        if sum(sizes) != A or min(sizes) < 1:
+            raise CldError(f"agent_collision: scene sizes {sizes} do not cover the {A} agents")
+        S = len(sizes)
+        start = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=self.device)
+        wv = c.get("weight", 1.0)
+        wts = torch.full((S,), float(wv), device=self.device) if np.isscalar(wv) else self._f32(torch.as_tensor(wv, dtype=torch.float32), (S,))
+        guided = None
+        if c.get("agents"):
+            gm = np.zeros(A, np.uint8)
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            for s_ in range(S):
+                sub = c["agents"].get(s_)
+                if sub is None:
+                    gm[offs[s_]:offs[s_ + 1]] = 1
+                else:
+                    gm[offs[s_] + np.asarray(sub, dtype=np.int64)] = 1
+            guided = torch.from_numpy(gm).to(self.device)
+        cc = _lib.CldCollision(ext.data_ptr(), wfa.data_ptr(), spd.data_ptr(), start.data_ptr(), wts.data_ptr(),
+                               None if guided is None else guided.data_ptr(), S, N, int(c.get("num_disks", 5)), max(sizes),
+                               float(c.get("buffer_dist", 0.2)), float(c.get("decay_rate", 0.9)), float(c.get("guide_moving_speed_th", 0.5)))
+        return cc, (ext, wfa, spd, start, wts, guided)
+
+    def agent_collision(self, traj, collision: Mapping, grad_in=None, want_grad=True):
+        """Upstream's AgentCollisionLoss on decoded plans [B,52,6] (descaled, sample-minor rows) -> (per-agent values [B] as
+        upstream files them under guide_losses, d total / d traj [B,52,6]); cld_agent_collision."""
+        traj = self._f32(traj)
+        B = traj.shape[0]
+        traj = self._f32(traj, (B, T, 6))
+        cc, keep = self._collision(collision, B)
+        gi = None if grad_in is None else self._f32(grad_in, (B, T, 6))
+        loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        grad = torch.empty(B, T, 6, dtype=torch.float32, device=self.device) if want_grad else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_agent_collision(self._h, _ptr(traj), C.byref(cc), _ptr(gi), _ptr(loss), _ptr(grad), B, self._stream()),
+                        "cld_agent_collision")
+        return (loss, grad) if want_grad else loss
 
     def guidance_losses(self, traj, guidance: Mapping):
         """Per-agent values of the built-in guidance losses on decoded trajectories [B,52,6] (descaled) -> [B,4] =

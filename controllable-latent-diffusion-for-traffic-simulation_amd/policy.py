@@ -115,7 +115,8 @@ class CldPolicy:
         """Upstream `set_guidance` (algos.py; guidance_loss.py:2106-2175): keep a guidance configuration for the following
         `get_action` calls.  `opt`: lr / optimizer / perturb_th of the optimiser step (scene_edit_config.py:74-90), `output`
         (True | dict: guidance on the t = 0 output, upstream apply_guidance_output + final_step_opt_params), `intermediate`."""
-        self._guidance = dict(guidance_from_config(guidance_config_list, scene_index), **opt)
+        data_batch = opt.pop("data_batch", None)         # observation fields scene-coupled losses read (agent_collision: extent, world_from_agent, curr_speed)
+        self._guidance = dict(guidance_from_config(guidance_config_list, scene_index, data_batch=data_batch), **opt)
         self._guidance_cfg = (guidance_config_list, torch.as_tensor(scene_index).reshape(-1).cpu())
 
     def clear_guidance(self):
@@ -125,8 +126,13 @@ class CldPolicy:
     def _guide_losses(self, traj, g, B: int, N: int, from_cfg: bool):
         """-> (guide_losses dict name -> [B,N] as upstream keys them, per-scene loss names) from the library's per-agent values;
         `g`: the guidance dict with its per-agent tensors repeated num_samp times."""
-        vals = self.vae.engine.guidance_losses(traj.reshape(B * N, 52, 6), g).reshape(B, N, 4)
+        has_builtin = any(g.get(k) is not None for k in ("target_speed", "speed_limit", "acc_limit", "target_pos"))
+        vals = (self.vae.engine.guidance_losses(traj.reshape(B * N, 52, 6), g).reshape(B, N, 4) if has_builtin
+                else torch.full((B, N, 4), float("nan"), device=traj.device))
         nan = torch.full((B, N), float("nan"), device=vals.device)
+        colv = None
+        if g.get("agent_collision") is not None:     # per-agent values as upstream files them (unweighted; :2166-2168)
+            colv = self.vae.engine.agent_collision(traj.reshape(B * N, 52, 6), dict(g["agent_collision"], num_samp=N), want_grad=False).reshape(B, N)
         out, names = {}, []
         if from_cfg:
             cfg_list, scene_index = self._guidance_cfg
@@ -139,13 +145,17 @@ class CldPolicy:
                     mask = torch.zeros(B, dtype=torch.bool)
                     mask[idx] = True
                     mask = mask.to(vals.device)
-                    out["%s_scene_%03d_%02d" % (c["name"], si, gi)] = torch.where(mask[:, None], vals[..., LOSS_COLUMN[c["name"]]], nan)
+                    v = colv if c["name"] == "agent_collision" else vals[..., LOSS_COLUMN[c["name"]]]
+                    out["%s_scene_%03d_%02d" % (c["name"], si, gi)] = torch.where(mask[:, None], v, nan)
         else:       # a plain `guidance=` dict: one scene, one entry per active term
             names.append([])
             for nm, col in (("target_speed", 0), ("speed_limit", 1), ("acc_limit", 2), ("target_pos", 3)):
                 if bool((~torch.isnan(vals[..., col])).any()):
                     out["%s_scene_000_%02d" % (nm, len(names[0]))] = vals[..., col]
                     names[0].append(nm)
+            if colv is not None:
+                out["agent_collision_scene_000_%02d" % len(names[0])] = colv
+                names[0].append("agent_collision")
         return out, names
 
     @torch.no_grad()
@@ -156,10 +166,12 @@ class CldPolicy:
         `guidance=`) the guidance losses of every sample are evaluated on the final output (diffuser.py:924-926), returned as
         info['guide_losses'], and the executed sample is the one `choose_action_from_guidance` picks (algos.py:2057-2064);
         `guide_as_filter_only`: sample without guidance and only filter (algos.py:1815); `guide_with_gt`: the sample closest to
-        obs_dict['target_positions'] (algos.py:2055-2056).  Not built: `guide_clean` (guiding the predicted clean trajectory,
-        diffuser.py:866-869) and `plan` -- they raise instead of being ignored."""
-        if guide_clean:
-            raise NotImplementedError("guide_clean (guidance on the predicted clean trajectory, diffuser.py:866-869) is not built")
+        obs_dict['target_positions'] (algos.py:2055-2056); `guide_clean=True`: the guidance steps act on the model's clean
+        prediction (diffuser.py:866-873; its "video_diff" variant, which re-derives the posterior, is not built and raises).  A
+        collision config (`agent_collision`, guidance_loss.py:442-630) is filed under guide_losses and makes the sample choice
+        scene-level, as upstream's SCENE_LEVEL_LOSSES do.  Not built: `plan` -- it raises instead of being ignored."""
+        if guide_clean not in (False, True, 0, 1, None):
+            raise NotImplementedError(f"guide_clean={guide_clean!r}: only the boolean form is built (diffuser.py:866-873)")
         if plan is not None:
             raise NotImplementedError("plan conditioning is not part of the CLD sampler")
         if kwargs:
@@ -176,6 +188,8 @@ class CldPolicy:
             aux["non_cond_feat"] = eng.non_cond_feat(cs)            # upstream builds it itself (diffuser.py:390-411,459-471); raises without the ContextEncoder weights
         B, N = cond.shape[0], int(num_action_samples)
         g = guidance if guidance is not None else self._guidance
+        if g is not None and guide_clean:
+            g = dict(g, guide_clean=True)
         out = self.dm({"history_positions": cond}, {k: aux[k] for k in ("cond_feat", "curr_states", "non_cond_feat") if k in aux},
                       {"num_samp": N}, noise=noise, class_free_guide_w=class_free_guide_w,
                       guidance=None if guide_as_filter_only else g)
@@ -247,7 +261,7 @@ def closed_loop_rollout(policy: CldPolicy, cond_fn: Callable, centroid, yaw, cur
     return torch.stack(poses)
 
 
-def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52) -> dict:
+def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, data_batch: Optional[Mapping] = None) -> dict:
     """Upstream's guidance configuration -> the `guidance=` dict of `DmModel.forward` / `Engine.sample`.
 
     `guidance_config_list` is what `DiffuserTrafficModel.set_guidance` takes (`src/tbsim/algos/algos.py`, built by
@@ -255,8 +269,10 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52) -
     `{'name', 'weight', 'params', 'agents'}` dicts; `scene_index [B]` maps agents to scenes (consecutive runs).  Each loss
     is averaged over the agents it applies to within its scene and multiplied by its weight; that is folded into the
     per-agent scales of the kernel: weight / (agents * horizon) for the per-step losses, weight / agents for the waypoint
-    losses.  Supported names: target_speed, speed_limit, acc_limit, target_pos_at_time, target_pos (the others couple
-    agents or sample the raster and are not built).  One speed / acceleration limit value per call."""
+    losses.  Supported names: target_speed, speed_limit, acc_limit, target_pos_at_time, target_pos, and agent_collision (needs
+    `data_batch` with `extent`, `world_from_agent`, `curr_speed`: the observation fields upstream's loss reads,
+    guidance_loss.py:506-510; at most one per scene, one parameter set per call); the others (map collision, social groups, stop
+    signs, ...) sample the raster or are not built.  One speed / acceleration limit value per call."""
     scene_index = torch.as_tensor(scene_index).reshape(-1).cpu()
     B = scene_index.numel()
     _, local = torch.unique_consecutive(scene_index, return_inverse=True)
@@ -266,6 +282,7 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52) -
     ts_scale = torch.zeros(B); ts = torch.zeros(B, horizon); has_ts = False
     sl_scale = torch.zeros(B); al_scale = torch.zeros(B); sl = al = None
     tp = torch.zeros(B, 2); tt = torch.zeros(B, dtype=torch.int32); tp_scale = torch.zeros(B); has_tp = False
+    col = None
     for si, cfgs in enumerate(guidance_config_list):
         members = torch.nonzero(local == si).reshape(-1)
         for cfg in cfgs:
@@ -299,9 +316,27 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52) -
                     tt[idx] = -(int(float(prm.get("min_target_time", 0.0)) * horizon) + 1)
                 tp_scale[idx] = wgt / n
                 has_tp = True
+            elif name == "agent_collision":
+                if data_batch is None or any(k not in data_batch for k in ("extent", "world_from_agent", "curr_speed")):
+                    raise ValueError("agent_collision needs data_batch with extent, world_from_agent and curr_speed")
+                if prm.get("excluded_agents") is not None:
+                    raise NotImplementedError("agent_collision: excluded_agents is not built")
+                S = int(local.max()) + 1
+                key = (int(prm.get("num_disks", 5)), float(prm.get("buffer_dist", 0.2)), float(prm.get("decay_rate", 0.9)), float(prm.get("guide_moving_speed_th", 0.5)))
+                if col is None:
+                    col = dict(extent=data_batch["extent"], world_from_agent=data_batch["world_from_agent"], curr_speed=data_batch["curr_speed"],
+                               scene_index=scene_index, weight=[0.0] * S, agents={}, num_disks=key[0], buffer_dist=key[1], decay_rate=key[2],
+                               guide_moving_speed_th=key[3])
+                elif (col["num_disks"], col["buffer_dist"], col["decay_rate"], col["guide_moving_speed_th"]) != key:
+                    raise ValueError("one agent_collision parameter set per call")
+                if col["weight"][si] != 0.0:
+                    raise ValueError("two agent_collision losses on one scene")
+                col["weight"][si] = wgt
+                if agents is not None:
+                    col["agents"][si] = list(agents)
             else:
                 raise NotImplementedError(f"guidance loss '{name}' is not built (target_speed, speed_limit, acc_limit, "
-                                          f"target_pos_at_time, target_pos are)")
+                                          f"target_pos_at_time, target_pos, agent_collision are)")
     if has_ts:
         out["target_speed"], out["loss_scale"] = ts, ts_scale
     if sl is not None:
@@ -310,6 +345,9 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52) -
         out["acc_limit"] = (al, al_scale)
     if has_tp:
         out["target_pos"] = (tp, tt, tp_scale)
+    if col is not None:
+        col["agents"] = col["agents"] or None
+        out["agent_collision"] = col
     if not out:
         raise ValueError("no guidance loss configured")
     return out

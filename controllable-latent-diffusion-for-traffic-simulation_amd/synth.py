@@ -250,6 +250,47 @@ def make_inputs(B: int, seed: int = 1) -> dict:
     return {"cond_feat": cond, "curr_states": cs}
 
 
+def make_collision_scene(scene_sizes, seed: int = 1, spacing: float = 3.5) -> dict:
+    """Synthetic scene geometry for upstream's AgentCollisionLoss (src/tbsim/utils/guidance_loss.py:442-630): the agents of every
+    scene stand on a jittered grid `spacing` metres apart, all heading roughly the same way, so that the faster ones run into
+    the ones ahead within the 5.2-s horizon.  -> extent [B,3] (length, width, height), world_from_agent [B,3,3] (rotation by the
+    agent's world heading + its world position), scene_index [B] (consecutive blocks), curr_speed [B] (a few below the
+    0.5 m/s `guide_moving_speed_th`)."""
+    B = int(sum(scene_sizes))
+    ext = np.stack([uniform(seed, "col_len", (B,), 3.8, 5.2), uniform(seed, "col_wid", (B,), 1.7, 2.2), np.full((B,), 1.6, np.float32)], axis=1)
+    th = uniform(seed, "col_heading", (B,), -0.25, 0.25).astype(np.float64) + 0.6
+    pos = np.zeros((B, 2))
+    scene_index = np.zeros((B,), np.int64)
+    b = 0
+    for si, n in enumerate(scene_sizes):
+        cols = int(np.ceil(np.sqrt(n)))
+        for k in range(n):
+            pos[b] = (100.0 * si + spacing * (k % cols), spacing * (k // cols))
+            scene_index[b] = si
+            b += 1
+    pos += uniform(seed, "col_jitter", (B, 2), -0.6, 0.6)
+    W = np.zeros((B, 3, 3), np.float64)
+    W[:, 0, 0] = np.cos(th); W[:, 0, 1] = -np.sin(th); W[:, 1, 0] = np.sin(th); W[:, 1, 1] = np.cos(th)
+    W[:, :2, 2] = pos; W[:, 2, 2] = 1.0
+    speed = uniform(seed, "col_speed", (B,), 0.0, 12.0)
+    speed[::5] = 0.2                                    # stationary agents: no gradient to them, no loss of their own
+    return {"extent": ext.astype(np.float32), "world_from_agent": W.astype(np.float32), "scene_index": scene_index,
+            "curr_speed": speed.astype(np.float32)}
+
+
+def make_collision_trajectories(B: int, N: int, curr_speed, seed: int = 1) -> np.ndarray:
+    """[B,N,52,6] descaled (x, y, v, yaw, acc, yaw-rate) plans in the agent frame that drive forward at about curr_speed with
+    a little lateral and heading wobble, different per sample."""
+    dt = 0.1
+    v = np.clip(curr_speed[:, None, None] + np.cumsum(normal(seed, "colt_acc", (B, N, HORIZON)) * 0.4, axis=2), 0.0, 20.0)
+    yaw = np.cumsum(normal(seed, "colt_yr", (B, N, HORIZON)) * 0.02, axis=2)
+    x = np.cumsum(v * np.cos(yaw) * dt, axis=2)
+    y = np.cumsum(v * np.sin(yaw) * dt, axis=2)
+    acc = np.gradient(v, dt, axis=2)
+    yr = np.gradient(yaw, dt, axis=2)
+    return np.stack((x, y, v, yaw, acc, yr), axis=-1).astype(np.float32)
+
+
 def make_future(B: int, seed: int = 1) -> dict:
     """Synthetic ground-truth futures for the encoder path: a unicycle roll-out with smooth random controls in
     the agent frame -> target_positions [B,52,2], target_yaws [B,52,1], curr_speed [B]."""

@@ -213,7 +213,54 @@ typedef struct cld_guidance {
     float final_lr;
     float final_perturb_th;
     int32_t final_optimizer;
+    /* Round 3 (appended: a struct zero-initialised below this line keeps every earlier behaviour).
+     * grad_steps > 1: that many optimiser steps per guided denoising step, each on a fresh decode of the current iterate, with
+     * the optimiser's state carried across them as upstream's perturb() does (guidance_loss.py:2247-2278: ONE torch.optim.Adam
+     * per call -- moments and bias correction continue from step to step; the clip, when on, is taken around the initial mean).
+     * 0 and 1 both mean one step.  final_grad_steps: the same for the output step (final_step_opt_params). */
+    int32_t grad_steps;
+    int32_t final_grad_steps;
+    /* guide_clean != 0: upstream's `guide_clean=True` (diffuser.py:866-873): the optimiser steps act on the model's CLEAN
+     * prediction x0_hat = sqrt(1 / acp_t) x_t - sqrt(1 / acp_t - 1) eps instead of on the posterior mean, and x_{t-1} is that
+     * guided x0_hat + sigma_t z (upstream does not re-derive the posterior from it unless guide_clean == "video_diff", which is
+     * not built).  PARITY UNPINNED beyond the oracle's restatement: no shipped config turns it on. */
+    int32_t guide_clean;
+    /* AgentCollisionLoss (guidance_loss.py:442-630) as a term of the guidance loss: every guided step decodes the current
+     * iterate, evaluates the loss and its gradient w.r.t. the decoded plans on the device (cld_agent_collision) and feeds it
+     * to the step as ext_grad (added to a caller ext_grad).  NULL = no such term.  Counts as a loss term for the
+     * "at least one term" rule. */
+    const struct cld_collision* collision;
 } cld_guidance;
+
+/* Upstream's AgentCollisionLoss (src/tbsim/utils/guidance_loss.py:442-630) as configured through DiffuserGuidance
+ * (:2143-2172): agents are `num_disks` disks of radius width / 2 along their axis; two agents of one scene collide at a step when
+ * their closest disk centres are within r_i + r_j + buffer_dist; penalty 1 - dist / bound, weighted by decay_rate^t (normalised),
+ * summed over the steps, averaged over ALL agents of the batch (upstream's .mean(-1) over B), zero for agents slower than
+ * moving_speed_th.  total = sum over scenes of scene_weight[s] * mean over the scene's guided agents (x samples); stationary and
+ * unguided agents receive no gradient (:512-534).  Agents A = B / num_samp; rows of traj are sample-minor (row = agent * num_samp
+ * + sample), sample n of every agent living in scene copy n.  `excluded_agents` of upstream is not built. */
+typedef struct cld_collision {
+    const float* extent;            /* DEVICE [A,3] length, width, height                                                   */
+    const float* world_from_agent;  /* DEVICE [A,3,3] row-major (rotation + translation of the agent frame in the world)     */
+    const float* curr_speed;        /* DEVICE [A] m/s                                                                       */
+    const int32_t* scene_start;     /* DEVICE [num_scenes + 1]: agents scene_start[s] .. scene_start[s + 1] - 1 form scene s
+                                     * (consecutive blocks covering 0 .. A, as unique_consecutive(scene_index) implies)     */
+    const float* scene_weight;      /* DEVICE [num_scenes]: weight of the scene's agent_collision config, 0 = not guided    */
+    const uint8_t* guided;          /* DEVICE [A] or NULL: 1 = the agent is among the config's `agents` (NULL: all of them) */
+    int32_t num_scenes;
+    int32_t num_samp;
+    int32_t num_disks;              /* 1..8 (upstream default 5)                                                            */
+    int32_t max_scene_agents;       /* largest scene_start[s + 1] - scene_start[s] (sizes the kernel's LDS; <= 150)         */
+    float buffer_dist;              /* upstream default 0.2                                                                 */
+    float decay_rate;               /* 0.9                                                                                  */
+    float moving_speed_th;          /* 0.5                                                                                  */
+} cld_collision;
+
+/* The loss above on given plans: traj [B,52,6] descaled (what cld_decode returns) -> loss [B] = the per-agent values upstream
+ * files under `guide_losses` (unweighted; 0 for stationary agents) and grad [B,52,6] = d total / d traj (+ grad_in when given).
+ * Either output may be NULL. */
+int cld_agent_collision(cld_handle h, const float* traj, const cld_collision* c, const float* grad_in, float* loss, float* grad,
+                        int32_t B, void* stream);
 
 /* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */
 int cld_sample_guided(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,

@@ -423,16 +423,18 @@ def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, tap
 # f-3  sampling-time guidance (upstream diffuser.py:844-929, guidance_loss.py:219-254,2221-2282)
 # --------------------------------------------------------------------------- #
 def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Optional[Tensor], loss_scale: Optional[Tensor],
-                  lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None, target_pos=None):
-    """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282, grad_steps = 1) with decoder = `decode` and
+                  lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None, target_pos=None,
+                  collision: Optional[dict] = None, grad_steps: int = 1, num_samp: int = 1):
+    """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282) with decoder = `decode` and
     TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target| (+ optional SpeedLimitLoss / AccLimitLoss
-    terms, each a (limit, per-agent scale) pair); Adam's first step is
-    -lr * g / (|g| + 1e-8) (bias-corrected moments of a single gradient), SGD's -lr * g.  perturb_th None = the
+    terms, each a (limit, per-agent scale) pair; + `collision`: the agent_collision configs, see scene_collision_total).
+    grad_steps optimiser steps with the optimiser's state carried across them (:2247-2252: one torch.optim.Adam / SGD per
+    call): Adam with torch's defaults (betas 0.9 / 0.999, eps 1e-8, bias-corrected: m_k / (1 - 0.9^k) over
+    sqrt(v_k / (1 - 0.999^k)) + eps), whose FIRST step is -lr * g / (|g| + 1e-8); SGD's -lr * g.  perturb_th None = the
     reference's actual behaviour: its clip (:2275-2278) acts on x_guidance - x_initial, two names of one tensor
-    (:2239), so it never changes anything (the golden vectors confirm); a number clips the step as the code intends.
-    Returns (guided mean, gradient)."""
-    x = mean.clone().requires_grad_(True)
-    with torch.enable_grad():
+    (:2239), so it never changes anything (the golden vectors confirm); a number clips the accumulated step to +- that
+    around the initial mean, as the code intends.  Returns (guided mean, gradient of the first step)."""
+    def total(x):
         traj = decode(wdec, x, cond, cs, True)
         loss = traj.sum() * 0.0
         if target_speed is not None:
@@ -453,11 +455,32 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
                     e = traj[bb, -tb - 1:, :2] - p_[bb]
                     dist = e.norm(dim=-1)
                     loss = loss + (F.softmin(dist, dim=-1) * (e ** 2).sum(dim=-1)).mean() * s_[bb]
-        (g,) = torch.autograd.grad(loss, x)
-    delta = -lr * g / (g.abs() + 1e-8) if optimizer == "adam" else -lr * g
-    if perturb_th is not None:
-        delta = delta.clamp(-perturb_th, perturb_th)
-    return mean + delta, g
+        if collision is not None:
+            loss = loss + scene_collision_total(traj, collision, num_samp)
+        return loss
+
+    x = mean.clone()
+    m, v = torch.zeros_like(x), torch.zeros_like(x)
+    g_first = None
+    for k in range(1, grad_steps + 1):
+        xk = x.clone().requires_grad_(True)
+        with torch.enable_grad():
+            (g,) = torch.autograd.grad(total(xk), xk)
+        if g_first is None:
+            g_first = g
+        if optimizer == "adam":
+            if grad_steps == 1:
+                delta = -lr * g / (g.abs() + 1e-8)
+            else:
+                m = 0.9 * m + 0.1 * g
+                v = 0.999 * v + 0.001 * g * g
+                delta = -(lr / (1.0 - 0.9 ** k)) * m / (v.sqrt() / math.sqrt(1.0 - 0.999 ** k) + 1e-8)
+        else:
+            delta = -lr * g
+        x = x + delta
+        if perturb_th is not None:
+            x = mean + (x - mean).clamp(-perturb_th, perturb_th)
+    return x, g_first
 
 
 def sample_guided(w, wdec, sched, x_T: Tensor, noise: Tensor, cond: Tensor, cs: Tensor, target_speed: Tensor,
@@ -498,19 +521,26 @@ def sample_step(w, wdec, sched, x_t: Tensor, cond: Tensor, i: int, z: Optional[T
                 guidance_w: float = 0.0, guidance: Optional[dict] = None) -> dict:
     """ONE iteration of the loops above at timestep i on a given x_t (upstream p_sample, diffuser.py:844-929; with CFG and
     guidance off it is DmModel.x_Tminus1, dm_model.py:144-156).  guidance = dict(curr_states, target_speed, loss_scale | None,
-    lr | None, optimizer).  -> dict(mean [before guidance], sigma, x_next, and on a guided step mean_guided, grad)."""
+    lr | None, optimizer, grad_steps = 1, collision | None, guide_clean = False).  guide_clean: upstream's `guide_clean=True`
+    (diffuser.py:866-873): the steps act on the model's clean prediction x0_hat = sqrt(1 / acp) x_t - sqrt(1 / acp - 1) eps
+    (predict_start_from_noise, :710-719) and x_next is the guided x0_hat + sigma z; `mean` then reports x0_hat.
+    -> dict(mean [before guidance], sigma, x_next, and on a guided step mean_guided, grad)."""
     t = torch.full((x_t.shape[0],), i, dtype=torch.long)
     eps = unet_forward(w, x_t, cond, t)
     if non_cond is not None:
         eps = (1 + guidance_w) * eps - guidance_w * unet_forward(w, x_t, non_cond, t)
     mean = sched["x_t_cof"][i] * x_t - sched["noise_cof"][i] * eps
     sigma = float((0.5 * sched["posterior_log_variance_clipped"][i]).exp())
+    if guidance is not None and i > 0 and guidance.get("guide_clean"):
+        acp = sched["alphas_cumprod"][i]
+        mean = torch.sqrt(1.0 / acp) * x_t - torch.sqrt(1.0 / acp - 1) * eps
     out = {"mean": mean, "sigma": sigma}
     m = mean
     if guidance is not None and i > 0:
         lr = guidance.get("lr")
         m, g = guidance_step(wdec, mean, cond, guidance["curr_states"], guidance.get("target_speed"), guidance.get("loss_scale"),
-                             sigma if lr is None else lr, None, guidance.get("optimizer", "adam"))
+                             sigma if lr is None else lr, None, guidance.get("optimizer", "adam"),
+                             collision=guidance.get("collision"), grad_steps=guidance.get("grad_steps", 1))
         out["mean_guided"], out["grad"] = m, g
     out["x_next"] = m if (i == 0 or z is None) else m + sigma * z
     return out
@@ -544,6 +574,76 @@ def adam_step_budget(g: Tensor, lr: float, grad_tol: float) -> Tensor:
 # --------------------------------------------------------------------------- #
 # f-2  policy surface: guide-loss values, sample selection, world update, closed loop
 # --------------------------------------------------------------------------- #
+def transform_agents_to_world(pos: Tensor, yaw: Tensor, world_from_agent: Tensor):
+    """src/tbsim/utils/geometry_utils.py:458-483 -- [B,N,T,2] / [B,N,T,1] in the agent frames -> world positions and headings
+    (the heading through atan2 of the transformed unit vector, as upstream writes it)."""
+    R, t = world_from_agent[:, None, None, :2, :2], world_from_agent[:, None, None, :2, 2]
+    pos_w = (R @ pos.unsqueeze(-1)).squeeze(-1) + t
+    hvec = torch.cat([torch.cos(yaw), torch.sin(yaw)], dim=-1)
+    hw = (R @ hvec.unsqueeze(-1)).squeeze(-1)                      # (W h + origin) - origin
+    return pos_w, torch.atan2(hw[..., 1], hw[..., 0]).unsqueeze(-1)
+
+
+def agent_collision_loss(x: Tensor, extent: Tensor, world_from_agent: Tensor, curr_speed: Tensor, scene_index: Tensor,
+                         agt_mask: Optional[Tensor] = None, num_disks: int = 5, buffer_dist: float = 0.2, decay_rate: float = 0.9,
+                         moving_speed_th: float = 0.5) -> Tensor:
+    """AgentCollisionLoss.forward (src/tbsim/utils/guidance_loss.py:506-630) on x [B,N,T,6] = (x, y, v, yaw, acc, yaw-rate) in
+    the agent frames -> [B,N] (rows of agt_mask when given).  Every agent is `num_disks` disks of radius width / 2 along its
+    axis (:481-492); two agents of one scene collide at a step when their closest disk centres are within r_i + r_j +
+    buffer_dist, the penalty is 1 - dist / that bound, weighted by decay_rate ** t (normalised), summed over the steps and
+    AVERAGED over all B columns (:621), zero for agents slower than moving_speed_th (which also receive no gradient, :512-516;
+    nor do agents outside agt_mask, :523-534).  Sample n of every agent lives in scene copy n."""
+    B, N, T_, _ = x.shape
+    moving = curr_speed.abs() > moving_speed_th
+    x = torch.where(moving.view(B, 1, 1, 1), x, x.detach())
+    pos_w, yaw_w = transform_agents_to_world(x[..., :2], x[..., 3:4], world_from_agent)
+    if agt_mask is not None:
+        m = agt_mask.view(B, 1, 1, 1)
+        pos_w, yaw_w = torch.where(m, pos_w, pos_w.detach()), torch.where(m, yaw_w, yaw_w.detach())
+    rad = extent[:, 1] / 2.0
+    cmin, cmax = -(extent[:, 0] / 2.0) + rad, (extent[:, 0] / 2.0) - rad
+    frac = torch.linspace(0.0, 1.0, num_disks, dtype=x.dtype)
+    cx = torch.stack([torch.linspace(float(cmin[b]), float(cmax[b]), num_disks) for b in range(B)]).to(x.dtype)   # as init_disks builds them
+    del frac
+    cent = pos_w.unsqueeze(-2) + cx.view(B, 1, 1, num_disks, 1) * torch.cat([torch.cos(yaw_w), torch.sin(yaw_w)], dim=-1).unsqueeze(-2)   # [B,N,T,D,2]
+    pen_d = rad.view(B, 1) + rad.view(1, B) + buffer_dist
+    same = (scene_index.view(B, 1) == scene_index.view(1, B)) & ~torch.eye(B, dtype=torch.bool)
+    c = cent.permute(2, 1, 0, 3, 4)                                                      # [T,N,B,D,2]
+    d = (c[:, :, :, None, :, None, :] - c[:, :, None, :, None, :, :]).norm(dim=-1)        # [T,N,B,B,D,D]
+    pair = d.reshape(T_, N, B, B, num_disks * num_disks).min(dim=-1)[0]
+    hit = (pair <= pen_d) & same
+    pen = torch.where(hit, 1.0 - pair / pen_d, torch.zeros_like(pair))
+    wts = torch.tensor([decay_rate ** t for t in range(T_)], dtype=x.dtype)
+    wts = wts / wts.sum()
+    out = (pen * wts.view(T_, 1, 1, 1)).sum(0).mean(-1).transpose(0, 1)                  # [B,N]
+    out = torch.where(moving.view(B, 1), out, torch.zeros_like(out))
+    return out if agt_mask is None else out[agt_mask]
+
+
+def scene_collision_total(traj: Tensor, col: dict, num_samp: int = 1) -> Tensor:
+    """What DiffuserGuidance.compute_guidance_loss (guidance_loss.py:2143-2172) adds to the total for `agent_collision` configs:
+    sum over scenes of weight * mean over the scene's guided agents (and samples).  traj [B * num_samp, T, 6] sample-minor;
+    col: extent, world_from_agent, curr_speed, scene_index, scene_weight [S] (0 = scene not guided), agents (optional dict
+    scene -> local indices), and the loss parameters."""
+    BN = traj.shape[0]
+    B = BN // num_samp
+    x = traj.reshape(B, num_samp, traj.shape[1], 6)
+    _, local = torch.unique_consecutive(col["scene_index"], return_inverse=True)
+    tot = x.sum() * 0.0
+    kw = {k: col[k] for k in ("num_disks", "buffer_dist", "decay_rate", "moving_speed_th") if k in col}
+    for si, wgt in enumerate(col["scene_weight"]):
+        if float(wgt) == 0.0:
+            continue
+        mask = local == si
+        sub = (col.get("agents") or {}).get(si)
+        if sub is not None:
+            idx = torch.nonzero(mask, as_tuple=True)[0][torch.as_tensor(sub)]
+            mask = torch.zeros_like(mask)
+            mask[idx] = True
+        tot = tot + agent_collision_loss(x, col["extent"], col["world_from_agent"], col["curr_speed"], col["scene_index"], mask, **kw).mean() * float(wgt)
+    return tot
+
+
 def guidance_losses(traj: Tensor, target_speed: Optional[Tensor] = None, loss_scale: Optional[Tensor] = None, speed_limit=None,
                     acc_limit=None, target_pos=None) -> Tensor:
     """The unweighted per-agent values upstream's guidance losses return (what DiffuserGuidance.compute_guidance_loss stores in

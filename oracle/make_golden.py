@@ -459,6 +459,80 @@ def section_guide_losses(ref):
                           "target_pos": "uniform(in_seed,'gl_wp',(B,2),-5,25)", "target_time": wt.tolist(), "min_target_time": 0.25}, **out)
 
 
+def section_agent_collision(ref):
+    """Upstream's AgentCollisionLoss (src/tbsim/utils/guidance_loss.py:442-630) through DiffuserGuidance.compute_guidance_loss
+    (:2143-2172) on a synthetic [B,N,52,6] batch: two scenes of 6 and 4 agents, 2 samples; per-agent values, the weighted total
+    and its autograd gradient w.r.t. the trajectories -- with every agent of both scenes guided, and with only agents
+    [0, 2, 3] of scene 0 guided (the others then receive no gradient, :523-534)."""
+    with _refimport.redirect_stdout(_refimport.io.StringIO()):
+        import tbsim.utils.guidance_loss as gl
+    sizes, N = [6, 4], 2
+    B = sum(sizes)
+    sc = synth.make_collision_scene(sizes, IN_SEED)
+    db = {k: T(v) for k, v in sc.items()}
+    traj = T(synth.make_collision_trajectories(B, N, sc["curr_speed"], IN_SEED))
+    out = {}
+    # (two guided scenes in ONE DiffuserGuidance cannot be recorded: the loss detaches stationary agents by writing into its
+    #  input in place (:512-516), and the second scene's call does that to the tensor the first call's graph saved -- autograd
+    #  refuses the backward.  One guided scene per call, the other scene present in the batch, is what upstream can run.)
+    col = {"name": "agent_collision", "params": {"num_disks": 5, "buffer_dist": 0.2}}
+    for tag, cfgs in (("all", [[dict(col, weight=1.0, agents=None)], []]),
+                      ("scene1", [[], [dict(col, weight=2.0, agents=None)]]),
+                      ("subset", [[dict(col, weight=1.5, agents=[0, 2, 3])], []])):
+        g = gl.DiffuserGuidance(cfgs)
+        x = traj.clone().requires_grad_(True)
+        tot, per = g.compute_guidance_loss(x * 1.0, db)
+        tot.backward()
+        out[f"total_{tag}"] = tot.detach().reshape(1)
+        out[f"grad_{tag}"] = x.grad.clone()
+        for k, v in per.items():
+            out[f"{tag}_{k}"] = v
+    save("agent_collision", {"scenes": sizes, "N": N, "in_seed": IN_SEED, "scene": "synth.make_collision_scene(scenes, in_seed)",
+                             "traj": "synth.make_collision_trajectories(B, N, curr_speed, in_seed)", "num_disks": 5, "buffer_dist": 0.2,
+                             "decay_rate": 0.9, "moving_speed_th": 0.5, "all": {"weights": [1.0, 0.0]}, "scene1": {"weights": [0.0, 2.0]},
+                             "subset": {"weights": [1.5, 0.0], "agents": {"0": [0, 2, 3]}}}, **out)
+
+
+def section_guidance_multi(ref):
+    """PerturbationGuidance.perturb (guidance_loss.py:2221-2282) with grad_steps = 3 -- torch.optim.Adam / SGD carried across the
+    steps -- on the target-speed scenes of `guidance`, and with an agent_collision config (one and three steps): decoder hook =
+    the oracle's decode, scene geometry from synth.make_collision_scene with curr_speed = curr_states[:, 2]."""
+    with _refimport.redirect_stdout(_refimport.io.StringIO()):
+        import tbsim.utils.guidance_loss as gl
+    from oracle import cld_oracle as O
+    B, T_ = 8, 52
+    wdec = O.to_torch(synth.make_decoder_weights(W_SEED))
+    inp = synth.make_inputs(B, IN_SEED)
+    cond, cs = T(inp["cond_feat"]), T(inp["curr_states"])
+    mean = T(synth.normal(IN_SEED, "guide_mean", (B, T_, 4)))
+    tgt = synth.uniform(IN_SEED, "guide_target_speed", (B, T_), 0.0, 12.0)
+    sc = synth.make_collision_scene([3, 5], IN_SEED)
+    sc["curr_speed"] = inp["curr_states"][:, 2].copy()
+    db = {k: T(v) for k, v in sc.items()}
+    ts_cfg = [[{"name": "target_speed", "weight": 1.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None}],
+              [{"name": "target_speed", "weight": 2.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None}]]
+    col_cfg = [[{"name": "agent_collision", "weight": 30.0, "params": {"num_disks": 5, "buffer_dist": 0.2}, "agents": None}],
+               [{"name": "target_speed", "weight": 1.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B, T_), bool)}, "agents": None}]]
+    out = {}
+    dec = lambda x: O.decode(wdec, x, cond, cs, True)
+    ident = lambda x, data_batch, params, bsize, num_samp: x
+    for tag, cfgs, opt_name, lr, steps in (("ts_adam3", ts_cfg, "adam", 0.3, 3), ("ts_sgd3", ts_cfg, "sgd", 5.0, 3),
+                                           ("col_sgd1", col_cfg, "sgd", 2.0, 1), ("col_adam3", col_cfg, "adam", 0.1, 3)):
+        pg = gl.PerturbationGuidance(transform=ident, transform_params=None)
+        pg.set_guidance(cfgs)
+        xg, per = pg.perturb(mean.clone(), db, {"optimizer": opt_name, "lr": lr, "grad_steps": steps, "perturb_th": None}, num_samp=1, decoder=dec)
+        out[f"guided_{tag}"] = xg.detach()
+        if tag == "col_sgd1":
+            for k, v in per.items():
+                out[f"col_sgd1_{k}"] = v
+    save("guidance_multi", {"B": B, "w_seed": W_SEED, "in_seed": IN_SEED, "scenes": [3, 5], "mean": "normal(in_seed,'guide_mean')",
+                            "target_speed": "uniform(in_seed,'guide_target_speed',0,12)", "ts_weights": [1.0, 2.0],
+                            "scene": "synth.make_collision_scene([3,5], in_seed) with curr_speed = curr_states[:,2]",
+                            "col_weights": [30.0, 0.0], "col_scene1_target_speed_weight": 1.0,
+                            "cases": {"ts_adam3": ["adam", 0.3, 3], "ts_sgd3": ["sgd", 5.0, 3], "col_sgd1": ["sgd", 2.0, 1], "col_adam3": ["adam", 0.1, 3]},
+                            "decoder": "oracle.decode (pinned by decode.npz)"}, **out)
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -467,7 +541,8 @@ def main():
     if len(sys.argv) > 1:                               # regenerate only the named newer fixture(s)
         for name in sys.argv[1:]:
             {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride, "losses": section_losses,
-             "n50": section_n50, "small": section_small, "log_prob_t0": section_log_prob_t0, "select": section_select, "guide_losses": section_guide_losses}[name](ref)
+             "n50": section_n50, "small": section_small, "log_prob_t0": section_log_prob_t0, "select": section_select, "guide_losses": section_guide_losses,
+             "agent_collision": section_agent_collision, "guidance_multi": section_guidance_multi}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
@@ -481,6 +556,8 @@ def main():
     section_log_prob_t0(ref)
     section_select(ref)
     section_guide_losses(ref)
+    section_agent_collision(ref)
+    section_guidance_multi(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

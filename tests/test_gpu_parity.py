@@ -1066,7 +1066,7 @@ def test_get_action_rejects_what_it_does_not_implement(eng10):
     inp = synth.make_inputs(B, 2)
     obs = {"cond_feat": torch.from_numpy(inp["cond_feat"]).cuda(), "curr_states": torch.from_numpy(inp["curr_states"]).cuda()}
     with pytest.raises(NotImplementedError):
-        pol.get_action(obs, guide_clean=True)
+        pol.get_action(obs, guide_clean="video_diff")      # only the boolean form of guide_clean is built (tests/test_gpu_collision.py)
     with pytest.raises(NotImplementedError):
         pol.get_action(obs, plan=object())
     with pytest.raises(TypeError):

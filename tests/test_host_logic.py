@@ -180,11 +180,17 @@ def test_guidance_struct_matches_header():
     assert [n for n, _ in g._fields_] == ["curr_states", "target_speed", "loss_scale", "lr", "perturb_th", "optimizer",
                                           "speed_limit", "acc_limit", "speed_limit_scale", "acc_limit_scale",
                                           "target_pos", "target_time", "target_pos_scale", "ext_grad",
-                                          "apply_output", "no_intermediate", "final_lr", "final_perturb_th", "final_optimizer"]
-    assert ctypes.sizeof(g) == 120 and g.apply_output.offset == 96 and g.final_optimizer.offset == 112 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
+                                          "apply_output", "no_intermediate", "final_lr", "final_perturb_th", "final_optimizer",
+                                          "grad_steps", "final_grad_steps", "guide_clean", "collision"]
+    assert ctypes.sizeof(g) == 136 and g.apply_output.offset == 96 and g.final_optimizer.offset == 112 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
+    assert g.grad_steps.offset == 116 and g.guide_clean.offset == 124 and g.collision.offset == 128      # appended in round 3: the earlier layout is untouched
+    c = _lib.CldCollision
+    assert [n for n, _ in c._fields_] == ["extent", "world_from_agent", "curr_speed", "scene_start", "scene_weight", "guided", "num_scenes",
+                                          "num_samp", "num_disks", "max_scene_agents", "buffer_dist", "decay_rate", "moving_speed_th"]
+    assert ctypes.sizeof(c) == 80 and c.num_scenes.offset == 48 and c.buffer_dist.offset == 64
     hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
     body = hdr[hdr.index("typedef struct cld_guidance {"):hdr.index("} cld_guidance;")]
-    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad|apply_output|no_intermediate|final_lr|final_perturb_th|final_optimizer);", body)] == [n for n, _ in g._fields_]
+    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad|apply_output|no_intermediate|final_lr|final_perturb_th|final_optimizer|grad_steps|final_grad_steps|guide_clean|collision);", body)] == [n for n, _ in g._fields_]
 
 
 def test_timers_keep_the_reference_surface():
@@ -225,8 +231,15 @@ def test_guidance_config_adapter_matches_the_golden_configurations():
     assert tt.tolist() == [10, 51, 30, 0, -27, 0, -27, 0]                    # scene 1: agents 1 and 3 of the scene, m = 26
     assert torch.allclose(sc, torch.tensor([2.0 / 3] * 3 + [0.0, 0.25, 0.0, 0.25, 0.0]))
     assert torch.equal(pos[4], torch.tensor([0.0, 1.0])) and torch.equal(pos[6], torch.tensor([2.0, 3.0]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                                          # the loss reads observation fields: they must be handed over
         guidance_from_config([[{"name": "agent_collision", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
+    with pytest.raises(NotImplementedError):
+        guidance_from_config([[{"name": "map_collision", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
+    db = {"extent": torch.ones(B, 3), "world_from_agent": torch.eye(3).expand(B, 3, 3), "curr_speed": torch.ones(B)}
+    g = guidance_from_config([[{"name": "agent_collision", "weight": 3.0, "params": {"num_disks": 4}, "agents": [0, 2]}],
+                              [{"name": "speed_limit", "weight": 3.0, "params": {"speed_limit": 6.0}, "agents": None}]], scene_index, data_batch=db)
+    c = g["agent_collision"]
+    assert c["weight"] == [3.0, 0.0] and c["agents"] == {0: [0, 2]} and c["num_disks"] == 4 and c["buffer_dist"] == 0.2 and "speed_limit" in g
     with pytest.raises(ValueError):
         guidance_from_config([[]], scene_index)
 

@@ -435,3 +435,73 @@ def test_world_step_matches_the_env_update():
         assert np.abs(world[b, :2].numpy() - xy).max() <= 1e-4
         assert abs(float(world[b, 2]) - (y64[b] + t64[b, k, 3])) <= 1e-5
     assert torch.equal(cs[:, 2], traj[:, k, 2]) and float(cs[:, [0, 1, 3]].abs().max()) == 0.0
+
+
+def collision_inputs(meta, scenes=None):
+    """Scene geometry + plans of the `agent_collision` fixture (or of the guidance_multi fixture when `scenes` is given:
+    curr_speed then follows curr_states)."""
+    sizes = scenes or meta["scenes"]
+    sc = synth.make_collision_scene(sizes, meta["in_seed"])
+    return {k: torch.from_numpy(v) for k, v in sc.items()}
+
+
+@pytest.mark.parametrize("tag", ["all", "scene1", "subset"])
+def test_agent_collision_loss_vs_reference(golden, tag):
+    """f-3 widening: upstream's AgentCollisionLoss through DiffuserGuidance (make_golden.section_agent_collision): per-agent
+    values, the weighted total and its gradient w.r.t. the plans -- one guided scene, the other scene of the batch guided, and a
+    guided subset of a scene (the rest then receives no gradient)."""
+    meta, g = golden("agent_collision")
+    db = collision_inputs(meta)
+    B, N = sum(meta["scenes"]), meta["N"]
+    traj = torch.from_numpy(synth.make_collision_trajectories(B, N, db["curr_speed"].numpy(), meta["in_seed"]))
+    col = dict(db, scene_weight=meta[tag]["weights"], agents={int(k): v for k, v in meta[tag].get("agents", {}).items()})
+    x = traj.reshape(B * N, 52, 6).clone().requires_grad_(True)
+    tot = O.scene_collision_total(x, col, N)
+    (grad,) = torch.autograd.grad(tot, x)
+    assert abs(float(tot) - float(g[f"total_{tag}"][0])) <= 1e-7
+    assert np.abs(grad.reshape(B, N, 52, 6).numpy() - g[f"grad_{tag}"]).max() <= 2e-7 * max(1.0, 1e3 * np.abs(g[f"grad_{tag}"]).max())
+    si = 1 if tag == "scene1" else 0
+    per = g[f"{tag}_agent_collision_scene_{si:03d}_00"]                        # NaN outside the guided agents
+    vals = O.agent_collision_loss(traj, db["extent"], db["world_from_agent"], db["curr_speed"], db["scene_index"]).numpy()
+    ok = ~np.isnan(per)
+    assert ok.sum() == (3 if tag == "subset" else meta["scenes"][si]) * N
+    assert np.abs(vals[ok] - per[ok]).max() <= 1e-7
+    if tag == "subset":                                                         # agents 1, 4, 5 of scene 0 and all of scene 1: detached
+        untouched = np.ones(B, bool); untouched[[0, 2, 3]] = False
+        assert np.abs(g["grad_subset"][untouched]).max() == 0.0 and np.abs(grad.reshape(B, N, 52, 6).numpy()[untouched]).max() == 0.0
+
+
+def guidance_multi_inputs(meta):
+    B = meta["B"]
+    inp = synth.make_inputs(B, meta["in_seed"])
+    sizes = meta["scenes"]
+    db = collision_inputs(meta, sizes)
+    db["curr_speed"] = torch.from_numpy(inp["curr_states"][:, 2].copy())
+    ts_scale = np.concatenate([np.full(n, w / (n * 52), np.float32) for n, w in zip(sizes, meta["ts_weights"])])
+    col_ts_scale = np.concatenate([np.zeros(sizes[0], np.float32), np.full(sizes[1], meta["col_scene1_target_speed_weight"] / (sizes[1] * 52), np.float32)])
+    return (torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"]),
+            torch.from_numpy(synth.normal(meta["in_seed"], "guide_mean", (B, 52, 4))),
+            torch.from_numpy(synth.uniform(meta["in_seed"], "guide_target_speed", (B, 52), 0.0, 12.0)),
+            torch.from_numpy(ts_scale), torch.from_numpy(col_ts_scale), dict(db, scene_weight=meta["col_weights"]))
+
+
+@pytest.mark.parametrize("case", ["ts_adam3", "ts_sgd3", "col_sgd1", "col_adam3"])
+def test_guidance_multi_step_and_collision_vs_reference_perturb(golden, case):
+    """f-3 widening: the reference's perturb() with grad_steps = 3 (torch.optim.Adam / SGD state carried across the steps) and
+    with an agent_collision config driving the decoder hook (make_golden.section_guidance_multi)."""
+    meta, g = golden("guidance_multi")
+    cond, cs, mean, tgt, ts_scale, col_ts_scale, col = guidance_multi_inputs(meta)
+    wdec = O.to_torch(synth.make_decoder_weights(meta["w_seed"]))
+    opt, lr, steps = meta["cases"][case]
+    if case.startswith("ts_"):
+        xg, _ = O.guidance_step(wdec, mean, cond, cs, tgt, ts_scale, lr, None, opt, grad_steps=steps)
+    else:
+        xg, _ = O.guidance_step(wdec, mean, cond, cs, tgt, col_ts_scale, lr, None, opt, collision=col, grad_steps=steps)
+    err = np.abs(xg.numpy() - g[f"guided_{case}"])
+    if opt == "adam":
+        # Adam's step is sign-like where a gradient element is ~1e-8: such an element may land lr (x the later steps) away;
+        # everything else must match to rounding
+        assert (err > 5e-6).mean() <= 2e-3 and err.max() <= 3.5 * lr
+    else:
+        assert err.max() <= 5e-6
+    assert np.abs(g[f"guided_{case}"] - mean.numpy()).max() > 1e-3            # the guidance moved the mean
