@@ -41,6 +41,7 @@ struct ConvLayer {
 
 struct ResBlock { ConvLayer c0, c1, res; bool has_res = false; };
 constexpr long kProfStride = 10;
+constexpr int kChainSmall = 256;      // launch sets of at most this many rows take the one-agent chain tiles (use_chains / chain_tile)
 const char* const kResnet = "context_encoder.map_encoder.encoder_heads.map_model.";
 
 }  // namespace
@@ -287,7 +288,9 @@ std::vector<float> pack_conv_weights_split(F&& wget, int c_out, int cin_virtual,
 // 2-way K split (twice the workgroups, two per CU) below that.  Measured at B = 1,024: B 813k vs A 716k
 // step.agent/s; an 8-wave variant (32 columns, 4-way K split) was slower than B and is not built; the 8-wave
 // variant C (64 columns, 2-way K split) is taken for the widest layers where it fills the chip (below).
-bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
+inline bool c1c2_mult_of_64(const ConvLayer& l) { return l.c1_pad % 64 == 0 && l.c2 % 64 == 0; }     // 64-channel chunks never straddle the two sources
+
+bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g, int roles = 1 /* layers sharing the launch (conv_pair_kernel: 2) */) {
     *g = l.g;
     const long waves_a = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 64) * 4;
     auto set = [&](int kc, int nwn, int ks) { g->kc = kc; g->nwn = nwn; g->ks = ks; return true; };
@@ -340,10 +343,10 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
         const long wgs_b = (long)(b_pad / (MT / l.g.lm)) * (l.c_out / 32);
         int best = 0;
         double best_cost = 1e30;
-        for (int hm = 0; hm <= 2; ++hm) {
+        for (int hm = 0; hm <= 3; ++hm) {
             ConvGeom tg = *g; tg.half = hm;
             if (!conv_geom_supported(tg)) continue;
-            if (th && th[0] != '0' + hm && (th[0] == '0' || th[0] == '1' || th[0] == '2')) continue;
+            if (th && th[0] != '0' + hm && (th[0] == '0' || th[0] == '1' || th[0] == '2' || th[0] == '3')) continue;
             const long n = wgs_b << hm, rounds = (n + 255) / 256;
             const int nmt = ((208 >> hm) + 15) / 16;
             double cost = (double)rounds * nmt / (rounds == 1 ? 0.85 : 0.92);
@@ -354,6 +357,10 @@ bool pick_tiling(const ConvLayer& l, int b_pad, ConvGeom* g) {
         }
         if (cost_c <= best_cost) return set(32, 4, 2);
         g->half = best;
+        if (best == 3 && (wgs_b << 3) * roles <= 256 && c1c2_mult_of_64(l)) {     // tiling D: at most one workgroup per CU -> give it a second wave per SIMD
+            ConvGeom d = *g; d.kc = 64; d.nwn = 2; d.ks = 4;
+            if (conv_geom_supported(d)) return set(64, 2, 4);
+        }
         return true;
     }
     return false;
@@ -427,7 +434,7 @@ hipError_t launch_maybe_timed(cld_handle h, const ConvLayer& l, const ConvGeom& 
 hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const ConvLayer& lb, const ConvArgs& ab,
                     int b_pad, hipStream_t s) {
     ConvGeom ga, gb;
-    if (!pick_tiling(la, b_pad, &ga) || !pick_tiling(lb, b_pad, &gb)) return hipErrorInvalidValue;
+    if (!pick_tiling(la, b_pad, &ga, 2) || !pick_tiling(lb, b_pad, &gb, 2)) return hipErrorInvalidValue;
 #ifdef CLD_EXPERIMENTS      // diagnostics (tests/tools/debug_split.py): stop a U-Net evaluation after N launches
     static const int stop_after = getenv("CLD_DEBUG_STOP") ? atoi(getenv("CLD_DEBUG_STOP")) : 1 << 30;
     if (h->launch_counter >= stop_after) return hipSuccess;
@@ -462,8 +469,11 @@ bool use_chains(cld_handle h, int b_pad) {
     const int f = h->force_kernel[CLD_KERNEL_UNET];
     if (f == CLD_FORM_LAYERS) return false;
     if (f == CLD_FORM_CHAIN) return true;
-    return b_pad >= 1024;
+    return b_pad >= 1024 || b_pad <= kChainSmall;
 }
+// agents per chain workgroup: 4 (13 M-tiles per wave at L = 52: the throughput tile) or, for the small batches whose time is
+// the LENGTH of the dependent launch sequence, 1 (a quarter of the serial MFMA chain per stage, four times the workgroups)
+int chain_tile(cld_handle, int b_pad) { return b_pad <= kChainSmall ? 1 : 4; }
 
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
 // final_conv.0 activations [b_pad,52,64] in w.buf[7].
@@ -509,7 +519,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ca.keep = b[2]; ca.y = b[6];
         ca.stamps = (h->stamp_buf && h->stamp_layer == 0) ? h->stamp_buf : nullptr;
         h->launch_counter += 5;
-        e = launch_chain_head(ca, b_pad, s);
+        e = launch_chain_head(ca, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
     } else {
     {   // block 0: conv(4 -> 64) | conv(64 -> 64) + residual_conv(x), the 1x1 projection of the latent evaluated in the epilogue
@@ -560,7 +570,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ct.cbias = w.cb; ct.cb_stride = NCB; ct.tbias = tbr;
         ct.keep = b[2]; ct.eps = b[7];
         h->launch_counter += 6;
-        e = launch_chain_tail(ct, b_pad, s);
+        e = launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
         h->eps_in_buf7 = true;
     } else {

@@ -102,7 +102,7 @@ struct ChainHeadArgs {    // downs.0.0 + downs.0.1 + downs.0.2: latent [b_pad,52
     float* y;
     unsigned long long* stamps;   // diagnostic builds (-DCLD_STAMPS) only: 16 u64 per workgroup; null otherwise
 };
-hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, hipStream_t s);
+hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, int agents_per_tile /* 4 | 1 */, hipStream_t s);
 struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_conv: x [b_pad,26,64] -> eps [b_pad,52,4]
     const float* x;       // output of ups.1.0's first conv
     ChainStage st[3];     // conv (+ residual tensor = residual_conv of the block input, kept) | conv | conv (+ kept)
@@ -116,7 +116,7 @@ struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_c
     float* keep;          // b_pad * 1792 floats of per-thread spill
     float* eps;           // [b_pad,52,4] noise prediction
 };
-hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, hipStream_t s);
+hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile /* 4 | 1 */, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // small kernels (misc_kernels.hip)

@@ -127,6 +127,9 @@ __device__ __forceinline__ void s22_encode(const float (&v)[4], h4& hi, h4& lo) 
 // (tests/tools/emulate_split.py) at ~3.9x its in-loop rate (scripts/ubench/mfma_issue.hip, V5).
 template <int L_IN, int LM, int STRIDE, int NTAPS, int KC, int NWN, int KS, int EPI, int GS, int OSTR, int PADC, int AIN, int AOUT, int HM>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const int bx, const int by) {
+    // HM = 3: eighth-height tiles, 26 rows = 1.6 M-tiles (2 / 1 agents at L = 13 / 26): the small-batch tile -- at 64 agents
+    // the quarter-height launch of a 256-channel layer is 128 workgroups on 256 CUs, each wave a serial chain of 640 MFMAs
+    // (9.7 us of the launch's 16.4); the eighth-height launch spreads the same work over every CU
     // HM = 1: half-height tiles -- 104 GEMM rows (8 / 4 / 2 agents at L = 13 / 26 / 52) = 6.5 M-tiles, the last one half
     // empty (its upper 8 rows are computed on row 0's operands and never read back); twice the workgroups of a full tile,
     // taken when a full-height launch would leave the chip under two workgroups per CU
@@ -212,21 +215,27 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
         const_cast<float*>(p.x1) + (size_t)bx * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.x2 ? p.x2 : p.x1) + (size_t)bx * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
-    v4f st[NPIECE];
-    auto load_chunk = [&](int c) {
+    // Small tiles (HM >= 2: 4 or 2 M-tiles per wave) are latency-bound, not issue-bound: a chunk's MFMAs last 0.5-1k cycles,
+    // less than one trip to L2, so their activations are fetched TWO chunks ahead (two register sets, by chunk parity) and
+    // their weight fragments a whole chunk pair ahead (WD below); the throughput tiles keep one set and two fragments (they
+    // sit at the 256-register cap and have 1.7k cycles of MFMAs per iteration to hide behind).
+    constexpr bool DEEP = HM >= 2 && !SPLIT && !PADC && STRIDE == 1;
+    constexpr int NSET = DEEP ? 2 : 1;
+    v4f st[NSET][NPIECE];
+    auto load_chunk = [&](int c, int set = 0) {
         const int cv = c * KC;                          // virtual input channel of this chunk
         if (cv < p.c1_pad) {                            // wave-uniform: which source feeds the chunk
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
                 const v4f v = (i == NPIECE - 1) ? buf_load16(rs1, voff_last, PADC ? 0 : cv * 4)
                                                 : buf_load16(rs1, voff0, (PADC ? 0 : cv * 4) + i * pstep);
-                st[i] = real ? v : v4f{0.f, 0.f, 0.f, 0.f};
+                st[set][i] = real ? v : v4f{0.f, 0.f, 0.f, 0.f};
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i)
-                st[i] = (i == NPIECE - 1) ? buf_load16(rs2, voff_last, (cv - p.c1_pad) * 4)
-                                          : buf_load16(rs2, voff0, (cv - p.c1_pad) * 4 + i * pstep);
+                st[set][i] = (i == NPIECE - 1) ? buf_load16(rs2, voff_last, (cv - p.c1_pad) * 4)
+                                               : buf_load16(rs2, voff0, (cv - p.c1_pad) * 4 + i * pstep);
         }
     };
 
@@ -253,7 +262,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     // ---- prologue: chunk 0 and the first weight fragments go out first; the LDS-side address arithmetic
     //      (divisions by the row counts), the accumulator clear and the halo zeroing run under their latency ----
     load_chunk(0);
-    // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them
+    if (DEEP && 1 < nchunk) load_chunk(1, 1);
+    // B fragments run two (tap, group) iterations ahead of the MFMAs that consume them (WD for the small tiles)
     // (PADC: the whole layer is two fragments per N tile -- taps 0..3 x 4 channels, and tap 4; see pack_latent_conv_weights)
     v4f bq0 = PADC ? buf_load16(rsw, lane * 32, ntile_g * 2048) : (SPLIT ? wload_hi(0, 0) : wload(0, 0));
     v4f bq1 = PADC ? buf_load16(rsw, lane * 32 + 16, ntile_g * 2048)
@@ -298,10 +308,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     v4f acc[NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int set = 0) {
         float* A = lds + buf * ABUFP;
 #pragma unroll
-        for (int i = 0; i < NPIECE; ++i) *reinterpret_cast<v4f*>(A + soff[i]) = st[i];
+        for (int i = 0; i < NPIECE; ++i) *reinterpret_cast<v4f*>(A + soff[i]) = st[set][i];
     };
     // zero the gaps: the two leading rows, and behind every agent its two halo rows (+ the AEX floats)
     constexpr int GQ = (2 * KCP + AEX) / 4;             // 16-byte pieces per gap
@@ -405,6 +415,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
     v4f af[2][NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m]);
+    // weight-fragment ring: slot (iteration index within the chunk pair) % WD; WD divides 2 NIT, so the slot of every
+    // iteration of the unrolled pair is a compile-time constant.  WD = 2 is the two-deep queue of the throughput tiles.
+    constexpr int WD = DEEP ? 2 * NIT : 2;
+    v4f bq[WD];
+    bq[0] = bq0; bq[1 % WD] = bq1;
+#pragma unroll
+    for (int i = 2; i < WD; ++i) bq[i] = (i / NIT < nchunk) ? wload(0, i) : bq0;
 
     for (int c0 = 0; c0 < nchunk; c0 += CUNR) {
 #pragma unroll
@@ -427,10 +444,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
                     for (int m = 0; m < NMT; ++m)
                         af[0][m] = *reinterpret_cast<const v4f*>(ldsb + aoff[m] + abase + ((it / KGW) * KCP + 16 * KS * (it % KGW)) * 4);
                 }
-                const v4f bcur = bq0;
-                bq0 = bq1;
-                if (c + (it + 2) / NIT < nchunk) bq1 = wload(c, it + 2);
-                if (it == 0 && more) load_chunk(c + 1);      // next chunk's activations: in flight under this chunk's MFMAs
+                const int slot = (cu * NIT + it) % WD;
+                const v4f bcur = bq[slot];
+                if (c + (it + WD) / NIT < nchunk) bq[slot] = wload(c, it + WD);
+                if (DEEP) { if (it == 0 && c + 2 < nchunk) load_chunk(c + 2, cu); }      // two chunks ahead, into the set chunk c came from
+                else if (it == 0 && more) load_chunk(c + 1);      // next chunk's activations: in flight under this chunk's MFMAs
                 const bool in_chunk = it + 1 < NIT;
                 const bool fetch = !LEAN && (in_chunk || (XPF && more));
                 const int src = in_chunk ? abase + (((it + 1) / KGW) * KCP + 16 * KS * ((it + 1) % KGW)) * 4 : anext;
@@ -445,7 +463,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (it == (LEAN ? NIT - 1 : WIT) && more) {
-                    store_chunk(cu ^ 1);
+                    store_chunk(cu ^ 1, DEEP ? (cu ^ 1) : 0);
                     __syncthreads();
                 }
             }
@@ -571,22 +589,38 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, float* lds, const i
 
     if (EPI == EPI_GN_MISH) {
         // GroupNorm over (GS channels x LM rows) of one agent: two-pass, biased variance, eps 1e-5
-        // (torch.nn.GroupNorm as used in diffuser_helpers.py:61).
+        // (torch.nn.GroupNorm as used in diffuser_helpers.py:61).  The TPP lanes of an (agent, group) pair are one wave or less,
+        // except in the eighth-height tiles (HM = 3), where a pair spreads over TPP / 64 waves: those add their wave sums through
+        // a few floats of LDS behind the output tiles.
+        constexpr int TPW = TPP > 64 ? 64 : TPP;         // lanes of a pair inside one wave
+        float* xch = lds + KS * OTILE;                   // [2][waves] (the launcher allocates 64 floats behind the tiles)
+        auto pair_sum = [&](float x, int slot) {
+#pragma unroll
+            for (int o = 1; o < TPW; o <<= 1) x += __shfl_xor(x, o);
+            if constexpr (TPP > 64) {
+                if (lane == 0) xch[slot * 8 + wave] = x;
+                __syncthreads();
+                constexpr int WPP = TPP / 64;            // waves per pair
+                const int w0 = (wave / WPP) * WPP;
+                x = 0.f;
+#pragma unroll
+                for (int k = 0; k < WPP; ++k) x += xch[slot * 8 + w0 + k];
+            }
+            return x;
+        };
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int e = 0; e < VW; ++e) s += (i < NV - 1 || last_ok) ? v[i][e] : 0.f;
-#pragma unroll
-        for (int o = 1; o < TPP; o <<= 1) s += __shfl_xor(s, o);
+        s = pair_sum(s, 0);
         const float mean = s * (1.0f / (float)(GS * LM));
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
             for (int e = 0; e < VW; ++e) { const float d = v[i][e] - mean; ss += (i < NV - 1 || last_ok) ? d * d : 0.f; }
-#pragma unroll
-        for (int o = 1; o < TPP; o <<= 1) ss += __shfl_xor(ss, o);
+        ss = pair_sum(ss, 1);
         const float rstd = 1.0f / sqrtf(ss * (1.0f / (float)(GS * LM)) + 1e-5f);
         float add[VW], sc[VW], sh[VW];
 #pragma unroll
@@ -702,7 +736,7 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr int AG = (208 >> HM) / LM;
     constexpr int ABUF = conv_image_floats(L_IN, LM, STRIDE, KC, AIN, HM);   // image + dump row
     constexpr int OTILE = KS * 16 * (((208 >> HM) + 15) / 16) * (16 * NWN + 4);   // the epilogue's partial output tiles alias the A images
-    constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
+    constexpr size_t lds_bytes = sizeof(float) * ((size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE) + 64);   // + the GroupNorm exchange slots of the eighth-height tiles
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>;
     static bool attr_done = false;
@@ -724,7 +758,7 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     constexpr int AG = (208 >> HM) / LM;
     constexpr int ABUF = conv_image_floats(L_IN, LM, 1, KC, AIN, HM);
     constexpr int OTILE = KS * 16 * (((208 >> HM) + 15) / 16) * (16 * NWN + 4);
-    constexpr size_t lds_bytes = sizeof(float) * (size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE);
+    constexpr size_t lds_bytes = sizeof(float) * ((size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE) + 64);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT, HM>;
     static bool attr_done = false;
@@ -743,30 +777,41 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
 
 // pairs: (L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT), stride 1 on both sides
 #define CLD_PAIR_INSTANCES(X)                                         \
+    X(26, 26, 64, 2, 4, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
+    X(13, 13, 64, 2, 4, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
+    X(13, 13, 64, 2, 4, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
+    X(26, 26, 64, 2, 4, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
+    X(13, 13, 64, 2, 4, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 3) \
     X(26, 26, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
     X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
+    X(26, 26, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
     X(13, 13, 32, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
     X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
+    X(13, 13, 32, 2, 2, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
     X(13, 13, 32, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
     X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
+    X(13, 13, 32, 2, 2, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
     X(26, 26, 32, 4, 1, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 1) \
     X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 2) \
+    X(26, 26, 32, 2, 2, 8, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 0, 0, 3) \
     X(13, 13, 32, 4, 1, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
     X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 2) \
+    X(13, 13, 32, 2, 2, 16, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 3) \
     X(26, 26, 32, 4, 1, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 0) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 1) \
     X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 2) \
+    X(26, 26, 32, 2, 2, 8, 2, 0, 2, EPI_BIAS, 2, EPI_BIAS, 0, 0, 3) \
     X(26, 26, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
     X(13, 13, 64, 4, 1, 32, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
     X(13, 13, 64, 4, 1, 16, 1, 0, 5, EPI_GN_MISH, 1, EPI_BIAS, 1, 1, 0) \
@@ -804,9 +849,20 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
 //   tilings: A = (KC 32, NWN 4, KS 1) 64 columns, 4 waves   -- large batches (>= 2 workgroups per CU anyway)
 //            B = (KC 32, NWN 2, KS 2) 32 columns, 4 waves   -- twice the workgroups of A
 //            C = (KC 32, NWN 4, KS 2) 64 columns, 8 waves   -- the 256-channel k5 blocks at 1,024..2,047 agents (one per CU)
+//            D = (KC 64, NWN 2, KS 4) 32 columns, 8 waves, eighth-height tiles only -- small batches whose launches are at most
+//                one workgroup per CU: the second wave per SIMD covers the chunk barriers and LDS latencies a lone wave exposes
 //   (the template also supports KC 64 / NWN 2 / KS 4, measured slower than B, and NWN 8 / KS 1 -- 128 columns in an
 //    8-wave workgroup -- measured equal to A at 2,048 and 4,096 agents; neither is built)
 #define CLD_CONV_INSTANCES(X)                            \
+    X(26, 26, 1, 5, 64, 2, 4, EPI_GN_MISH, 16, 1, 0, 0, 0, 3) \
+    X(13, 13, 1, 5, 64, 2, 4, EPI_GN_MISH, 32, 1, 0, 0, 0, 3) \
+    X(13, 13, 1, 5, 64, 2, 4, EPI_GN_MISH, 16, 1, 0, 0, 0, 3) \
+    X(26, 26, 1, 5, 64, 2, 4, EPI_GN_MISH, 8, 1, 0, 0, 0, 3) \
+    X(26, 26, 1, 1, 64, 2, 4, EPI_BIAS, 16, 1, 0, 0, 0, 3) \
+    X(13, 13, 1, 1, 64, 2, 4, EPI_BIAS, 32, 1, 0, 0, 0, 3) \
+    X(13, 13, 1, 1, 64, 2, 4, EPI_BIAS, 16, 1, 0, 0, 0, 3) \
+    X(26, 26, 1, 1, 64, 2, 4, EPI_BIAS, 8, 1, 0, 0, 0, 3) \
+    X(13, 13, 1, 2, 64, 2, 4, EPI_BIAS, 16, 2, 0, 0, 0, 3) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 1, 0, 0, 1) \
@@ -819,10 +875,12 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 1) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 2) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 3) \
     X(13, 13, 1, 5, 32, 4, 1, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 1) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 2) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 3) \
     X(13, 13, 1, 5, 32, 4, 2, EPI_GN_MISH, 32, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 4, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 5, 32, 4, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
@@ -830,10 +888,12 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 1) \
     X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 2) \
+    X(13, 13, 1, 5, 32, 2, 2, EPI_GN_MISH, 16, 1, 0, 0, 0, 3) \
     X(26, 26, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 1) \
     X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 2) \
+    X(26, 26, 1, 5, 32, 2, 2, EPI_GN_MISH, 8, 1, 0, 0, 0, 3) \
     X(52, 52, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(52, 52, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
@@ -842,32 +902,39 @@ hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeo
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 2) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 3) \
     X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 1) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 2) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 32, 1, 0, 0, 0, 3) \
     X(13, 13, 1, 1, 32, 4, 1, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
     X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 2) \
+    X(13, 13, 1, 1, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 3) \
     X(26, 26, 1, 1, 32, 4, 1, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
     X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 2) \
+    X(26, 26, 1, 1, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 3) \
     X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 0) \
     X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 1) \
     X(52, 26, 2, 3, 32, 2, 2, EPI_BIAS, 8, 1, 0, 0, 0, 2) \
     X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 0) \
     X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 1) \
     X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 2) \
+    X(26, 13, 2, 3, 32, 2, 2, EPI_BIAS, 16, 1, 0, 0, 0, 3) \
     X(13, 13, 1, 2, 32, 4, 1, EPI_BIAS, 16, 2, 0, 0, 0, 0) \
     X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 0) \
     X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 1) \
     X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 2) \
+    X(13, 13, 1, 2, 32, 2, 2, EPI_BIAS, 16, 2, 0, 0, 0, 3) \
     X(26, 26, 1, 2, 32, 4, 1, EPI_BIAS, 8, 2, 0, 0, 0, 0) \
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 0) \
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 1) \
     X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 2) \
+    X(26, 26, 1, 2, 32, 2, 2, EPI_BIAS, 8, 2, 0, 0, 0, 3) \
     X(52, 52, 1, 5, 32, 4, 1, EPI_GN_MISH, 8, 1, 1, 0, 1, 0) \
     X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 1, 0) \
     X(52, 52, 1, 5, 64, 4, 1, EPI_GN_MISH, 8, 1, 0, 1, 0, 0) \

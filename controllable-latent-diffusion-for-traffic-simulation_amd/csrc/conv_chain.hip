@@ -68,48 +68,79 @@ __device__ __forceinline__ v4f bload16(__amdgpu_buffer_rsrc_t r, int voff, int s
     return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-// Geometry of a 64-channel tile of AG agents x L rows.  LDS image: rows of KCP floats; agent a's rows start at a * ASTR,
-// two zero rows lead every agent block (the next agent's lead rows are the previous one's trailing halo), AEX extra floats
-// per block keep the fragment reads conflict-free (scripts/lds_conflicts.py: L = 52 -> 0, L = 26 -> 16).
+// Geometry of a 64-channel tile of AG agents x L rows (AG = 4: the throughput tile, 13 M-tiles at L = 52; AG = 1: the
+// small-batch tile, one workgroup per agent).  LDS image: rows of KCP floats; agent a's rows start at a * ASTR, two zero rows
+// lead every agent block (the next agent's lead rows are the previous one's trailing halo), AEX extra floats per block keep the
+// fragment reads conflict-free (scripts/lds_conflicts.py: AG = 4: L = 52 -> 0, L = 26 -> 16; AG = 1: 16 consecutive rows of
+// 72 floats are conflict-free as they are).  M-tile m holds rows RPT m .. RPT m + RPT - 1 of every agent: GEMM row i of a tile
+// (lane i of a fragment read; accumulator register r of lane group q is row 4 q + r) is agent i % AG, row RPT m + i / AG.
 template <int L_, int AG_>
 struct Geo {
     static constexpr int C = 64, L = L_, AG = AG_;
     static constexpr int KCP = C + 8;
     static constexpr int LP = L + 2;
-    static constexpr int AEX = (L == 26) ? 16 : 0;
+    static constexpr int AEX = (AG == 4 && L == 26) ? 16 : 0;
     static constexpr int ASTR = LP * KCP + AEX;
     static constexpr int RPT = 16 / AG;                 // rows of one agent per M-tile
     static constexpr int NMT = (AG * L + 15) / 16;
-    static constexpr bool RAGGED = NMT * RPT != L;      // the last M-tile carries rows past the agent's end
-    static_assert(AG == 4, "register r = agent r (AG = 4) is what the in-register epilogue assumes");
+    static constexpr bool RAGGED = NMT * 16 != AG * L;  // the last M-tile carries rows past the agents' ends
+    static constexpr int IMG = (AG * LP + 2) * KCP + AG * AEX;
+    static_assert(AG == 4 || AG == 1, "tiles of 4 agents or of 1");
+    static __device__ __forceinline__ int agent(int q, int r) { return AG == 4 ? r : 0; }
+    static __device__ __forceinline__ int pos(int m, int q, int r) { return AG == 4 ? 4 * m + q : 16 * m + 4 * q + r; }
+    static __device__ __forceinline__ bool ok(int m, int q, int r) { return !RAGGED || m < NMT - 1 || pos(m, q, r) < L; }
+    // float offset of (agent, row) of accumulator register r of M-tile m relative to the lane's base  row0(q) * KCP
+    static constexpr int roff(int m, int r) { return AG == 4 ? r * ASTR + 4 * m * KCP : (16 * m + r) * KCP; }
+    static __device__ __forceinline__ int row0(int q) { return AG == 4 ? q : 4 * q; }
+    // fragment base (floats) of lane i16: agent i % AG, row i / AG of M-tile 0
+    static __device__ __forceinline__ int frag0(int i16) { return (i16 % AG) * ASTR + (i16 / AG) * KCP; }
 };
-constexpr int kImgFloats = (4 * 54 + 2 + 6) * 72;      // the L = 52 image + 6 slack rows (stride-2 / ragged fragment reads run past the last agent)
-static_assert(kImgFloats >= 4 * Geo<26, 4>::ASTR + 8 * 72, "the L = 26 image fits in the same allocation");
+constexpr int kSlackFloats = 16 * 72;       // rows behind the image that ragged / stride-2 fragment reads run into (read, never used)
+template <int AG> constexpr int img_floats() { return (Geo<52, AG>::IMG > Geo<26, AG>::IMG ? Geo<52, AG>::IMG : Geo<26, AG>::IMG) + kSlackFloats; }
+
+// Weight fragments run WD (tap, group) iterations ahead of the MFMAs that consume them: an iteration is 4 NMT MFMAs, i.e.
+// 128 NMT cycles of cover, and a fragment comes from L2 (~1.5k cycles) -- two iterations ahead is enough for the 13-M-tile
+// throughput tile and far too little for the 4- and 2-M-tile small-batch tiles, whose loop otherwise waits on every fragment.
+constexpr int weight_depth(int nmt, int nit) {
+    int d = (3400 + 128 * nmt - 1) / (128 * nmt);
+    d = d < 2 ? 2 : d;
+    return d > nit ? nit : d;
+}
+template <int NTAPS>
+__device__ __forceinline__ v4f wfrag_load(const __amdgpu_buffer_rsrc_t rsw, int wlane, int ntn, int ntile, int it) {
+    const int c = it / (2 * NTAPS), ii = it % (2 * NTAPS), t = ii / 2, g = ii % 2;
+    return bload16(rsw, wlane, (((2 * c + g) * NTAPS + t) * ntn + ntile) * 1024);
+}
+// the first WD fragments of a layer: issued by the caller BEFORE the previous layer's epilogue, so that a layer does not start
+// behind an L2 round trip
+template <int C_IN, int NTAPS, int NMT>
+struct WQueue {
+    static constexpr int NIT = (C_IN / 16) * NTAPS, WD = weight_depth(NMT, NIT);
+    v4f q[WD];
+    __device__ __forceinline__ void prime(const __amdgpu_buffer_rsrc_t rsw, int wlane, int ntn, int ntile) {
+#pragma unroll
+        for (int i = 0; i < WD; ++i) q[i] = wfrag_load<NTAPS>(rsw, wlane, ntn, ntile, i);
+    }
+};
 
 // K loop over an LDS-resident image: acc[m] += sum over (chunk c, tap t, group g) in conv_block.hip's order.
 // abase: byte address of this lane's fragment for (M-tile 0, tap 0, channel group 0); M-tile m is MSTEP bytes further.
 template <int KCP, int MSTEP, int C_IN, int NTAPS, int NMT>
 __device__ __forceinline__ void kloop(v4f (&acc)[NMT], const char* ldsb, const int abase, const __amdgpu_buffer_rsrc_t rsw,
-                                      const int wlane, const int ntn, const int ntile) {
-    constexpr int NIT = (C_IN / 16) * NTAPS;
+                                      const int wlane, const int ntn, const int ntile, WQueue<C_IN, NTAPS, NMT>& wq) {
+    constexpr int NIT = (C_IN / 16) * NTAPS, WD = WQueue<C_IN, NTAPS, NMT>::WD;
     auto loff = [](int it) {                 // LDS byte offset of iteration it = (chunk, tap, group)
         const int c = it / (2 * NTAPS), ii = it % (2 * NTAPS), t = ii / 2, g = ii % 2;
         return (t * KCP + 16 * (2 * c + g)) * 4;
     };
-    auto wload = [&](int it) {
-        const int c = it / (2 * NTAPS), ii = it % (2 * NTAPS), t = ii / 2, g = ii % 2;
-        return bload16(rsw, wlane, (((2 * c + g) * NTAPS + t) * ntn + ntile) * 1024);
-    };
-    v4f bq0 = wload(0), bq1 = wload(1);
     v4f af[2][NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m) af[0][m] = *reinterpret_cast<const v4f*>(ldsb + abase + m * MSTEP + loff(0));
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int cur = it & 1;
-        const v4f bcur = bq0;
-        bq0 = bq1;
-        if (it + 2 < NIT) bq1 = wload(it + 2);
+        const v4f bcur = wq.q[it % WD];
+        if (it + WD < NIT) wq.q[it % WD] = wfrag_load<NTAPS>(rsw, wlane, ntn, ntile, it + WD);
 #pragma unroll
         for (int g = 0; g < NMT; ++g) {
             if (it + 1 < NIT) af[cur ^ 1][g] = *reinterpret_cast<const v4f*>(ldsb + abase + g * MSTEP + loff(it + 1 < NIT ? it + 1 : 0));
@@ -152,20 +183,38 @@ __device__ __forceinline__ void gn_mish(v4f (&acc)[G::NMT], const float bias, co
     for (int m = 0; m < G::NMT; ++m) {
         v2f lo = v2f{acc[m][0], acc[m][1]} + bias2, hi = v2f{acc[m][2], acc[m][3]} + bias2;
         acc[m] = v4f{lo[0], lo[1], hi[0], hi[1]};
-        if (G::RAGGED && m == G::NMT - 1 && G::RPT * m + q >= G::L) { lo = v2f{0.f, 0.f}; hi = v2f{0.f, 0.f}; }
+        if (G::RAGGED && m == G::NMT - 1) {
+            lo = v2f{G::ok(m, q, 0) ? lo[0] : 0.f, G::ok(m, q, 1) ? lo[1] : 0.f};
+            hi = v2f{G::ok(m, q, 2) ? hi[0] : 0.f, G::ok(m, q, 3) ? hi[1] : 0.f};
+        }
         s01 += lo; s23 += hi;
     }
     const float inv = 1.0f / (float)(8 * G::L);
-    const v2f mean01 = {group_sum(s01[0]) * inv, group_sum(s01[1]) * inv}, mean23 = {group_sum(s23[0]) * inv, group_sum(s23[1]) * inv};
+    v2f mean01, mean23;
+    if (G::AG == 1) {                // the four registers are four rows of the one agent
+        const float mu = group_sum((s01[0] + s01[1]) + (s23[0] + s23[1])) * inv;
+        mean01 = v2f{mu, mu}; mean23 = mean01;
+    } else {
+        mean01 = v2f{group_sum(s01[0]) * inv, group_sum(s01[1]) * inv}; mean23 = v2f{group_sum(s23[0]) * inv, group_sum(s23[1]) * inv};
+    }
     v2f q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < G::NMT; ++m) {
         v2f lo = v2f{acc[m][0], acc[m][1]} - mean01, hi = v2f{acc[m][2], acc[m][3]} - mean23;
-        if (G::RAGGED && m == G::NMT - 1 && G::RPT * m + q >= G::L) { lo = v2f{0.f, 0.f}; hi = v2f{0.f, 0.f}; }
+        if (G::RAGGED && m == G::NMT - 1) {
+            lo = v2f{G::ok(m, q, 0) ? lo[0] : 0.f, G::ok(m, q, 1) ? lo[1] : 0.f};
+            hi = v2f{G::ok(m, q, 2) ? hi[0] : 0.f, G::ok(m, q, 3) ? hi[1] : 0.f};
+        }
         q01 += lo * lo; q23 += hi * hi;
     }
-    const v2f sc01 = {(1.0f / sqrtf(group_sum(q01[0]) * inv + 1e-5f)) * gam, (1.0f / sqrtf(group_sum(q01[1]) * inv + 1e-5f)) * gam};
-    const v2f sc23 = {(1.0f / sqrtf(group_sum(q23[0]) * inv + 1e-5f)) * gam, (1.0f / sqrtf(group_sum(q23[1]) * inv + 1e-5f)) * gam};
+    v2f sc01, sc23;
+    if (G::AG == 1) {
+        const float sc = (1.0f / sqrtf(group_sum((q01[0] + q01[1]) + (q23[0] + q23[1])) * inv + 1e-5f)) * gam;
+        sc01 = v2f{sc, sc}; sc23 = sc01;
+    } else {
+        sc01 = v2f{(1.0f / sqrtf(group_sum(q01[0]) * inv + 1e-5f)) * gam, (1.0f / sqrtf(group_sum(q01[1]) * inv + 1e-5f)) * gam};
+        sc23 = v2f{(1.0f / sqrtf(group_sum(q23[0]) * inv + 1e-5f)) * gam, (1.0f / sqrtf(group_sum(q23[1]) * inv + 1e-5f)) * gam};
+    }
     const v2f bet2 = {bet, bet}, add01 = {add[0], add[1]}, add23 = {add[2], add[3]}, two = {2.0f, 2.0f};
     auto mish2 = [&](const v2f x, const v2f ad) {          // x n / (n + 2) + ad, n = e^x (e^x + 2)   (conv_block.hip mish_f)
         const v2f c = v2f{fminf(x[0], 30.0f), fminf(x[1], 30.0f)} * v2f{1.4426950408889634f, 1.4426950408889634f};
@@ -187,11 +236,10 @@ __device__ __forceinline__ void gn_mish(v4f (&acc)[G::NMT], const float bias, co
 template <class G>
 __device__ __forceinline__ void to_image(const v4f (&acc)[G::NMT], float* lds, const int wbase, const int q) {
 #pragma unroll
-    for (int m = 0; m < G::NMT; ++m) {
-        if (G::RAGGED && m == G::NMT - 1 && G::RPT * m + q >= G::L) continue;
+    for (int m = 0; m < G::NMT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lds[wbase + r * G::ASTR + G::RPT * m * G::KCP] = acc[m][r];
-    }
+        for (int r = 0; r < 4; ++r)
+            if (G::ok(m, q, r)) lds[wbase + G::roff(m, r)] = acc[m][r];
 }
 
 template <class G>
@@ -211,33 +259,33 @@ __device__ __forceinline__ void zero_halo(float* lds, const int tid, const int n
 // ---------------------------------------------------------------------------------------------------------------------
 // downs.0 as one launch
 // ---------------------------------------------------------------------------------------------------------------------
+template <int AG>
 __global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs p) {
-    typedef Geo<52, 4> G;
+    typedef Geo<52, AG> G;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* xl = lds + kImgFloats;                        // the tile's latent rows [4][52][4]: operand of residual_conv in stage 1
+    float* xl = lds + img_floats<AG>();                  // the tile's latent rows [AG][52][4]: operand of residual_conv in stage 1
     const char* ldsb = reinterpret_cast<const char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = blockIdx.x * 4;
+    const int b0 = blockIdx.x * AG;
     const int n = 16 * wave + n16;                       // this lane's output channel
     CSTAMP(0);
     CSTAMP_RT(14);
 
     // ---- latent rows -> image channel slots 0..3 (+ a compact copy); halos zeroed once: no layer writes them ----
-    if (tid < 208) {
+    if (tid < AG * 52) {
         const int a = tid / 52, l = tid % 52;
         const v4f v = *reinterpret_cast<const v4f*>(p.x + ((size_t)(b0 + a) * 52 + l) * 4);
         *reinterpret_cast<v4f*>(lds + a * G::ASTR + (2 + l) * G::KCP) = v;
         *reinterpret_cast<v4f*>(xl + tid * 4) = v;
     }
     zero_halo<G>(lds, tid, 256);
-    for (int i = tid; i < 6 * G::KCP / 4; i += 256)      // slack rows behind the image (read by the stride-2 layer's last M-tile, never used)
-        *reinterpret_cast<v4f*>(lds + (4 * 54 + 2) * G::KCP + i * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < kSlackFloats / 4; i += 256)    // slack rows behind the image (read by ragged / stride-2 fragments, never used)
+        *reinterpret_cast<v4f*>(lds + G::IMG + i * 4) = v4f{0.f, 0.f, 0.f, 0.f};
 
     v4f acc[G::NMT];
-    // fragment base of this lane: agent n16 % 4, row n16 / 4 of M-tile 0; lane group q takes channels 4q.. of a 16-channel group
-    const int arow = (n16 % 4) * G::ASTR + (n16 / 4) * G::KCP;                 // floats, relative to the agent block's row 0 (= first halo row)
-    const int wbase = (2 + q) * G::KCP + n;                                    // epilogue: (agent 0, row q, channel n)
+    const int arow = G::frag0(n16);                      // floats, relative to the agent block's row 0 (= first halo row)
+    const int wbase = (2 + G::row0(q)) * G::KCP + n;     // epilogue: register (m, r) of this lane lives at wbase + roff(m, r)
     constexpr int MSTEP = G::RPT * G::KCP * 4;
 
     // ---- stage 0: Conv1d(4 -> 64, k5) with K folded over (tap, channel) (conv_block.hip PADC) ----
@@ -261,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs 
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(*reinterpret_cast<const float*>(ldsb + ab + m * MSTEP + t4), bq1[0], acc[m], 0, 0, 0);
         float add[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + r) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
+        for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + G::agent(q, r)) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
         gn_mish<G>(acc, st.bias[n], st.gamma[n], st.beta[n], add, q);
         __syncthreads();                                 // every wave has read the latent slots
         to_image<G>(acc, lds, wbase, q);
@@ -270,19 +318,26 @@ __global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs 
     CSTAMP(1);
 
     // ---- stages 1..3: Conv1d(64 -> 64, k5) + GroupNorm + Mish [+ time / cond vector] [+ residual]; one code instance ----
-    v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * 13 * 256 + tid;
+    v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * G::NMT * 256 + tid;
+    typedef Geo<26, AG> GO;
+    WQueue<64, 5, G::NMT> wq;
+    WQueue<64, 3, GO::NMT> wqd;
+    wq.prime(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.st[1].wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000), lane * 16, 4, wave);
 #pragma clang loop unroll(disable)
     for (int s = 1; s <= 3; ++s) {
         const ChainStage& st = p.st[s];
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
 #pragma unroll
         for (int m = 0; m < G::NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
-        kloop<G::KCP, MSTEP, 64, 5, G::NMT>(acc, ldsb, (arow + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        kloop<G::KCP, MSTEP, 64, 5, G::NMT>(acc, ldsb, (arow + 4 * q) * 4, rsw, lane * 16, 4, wave, wq);
+        // the next layer's first weight fragments travel under this layer's epilogue
+        if (s < 3) wq.prime(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.st[s + 1].wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000), lane * 16, 4, wave);
+        else wqd.prime(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.st[4].wfrag), 0, 4 * 3 * 4 * 1024, 0x00020000), lane * 16, 4, wave);
         CSTAMP(2 * s);
         float add[4] = {0.f, 0.f, 0.f, 0.f};
         if (st.cb_off >= 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + r) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
+            for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + G::agent(q, r)) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
         }
         gn_mish<G>(acc, st.bias[n], st.gamma[n], st.beta[n], add, q);
         if (st.res_kind == CHAIN_RES_LATENT) {
@@ -293,7 +348,8 @@ __global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs 
             for (int m = 0; m < G::NMT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const v4f x4 = *reinterpret_cast<const v4f*>(xl + (r * 52 + 4 * m + q) * 4);
+                    if (!G::ok(m, q, r)) continue;
+                    const v4f x4 = *reinterpret_cast<const v4f*>(xl + (G::agent(q, r) * 52 + G::pos(m, q, r)) * 4);
                     // explicit FMAs: whatever the vectoriser does with the four agents of a register quad, every element
                     // sees the same operation sequence (a row's result must not depend on its place in the tile)
                     acc[m][r] += fmaf(w4[3], x4[3], fmaf(w4[2], x4[2], fmaf(w4[1], x4[1], fmaf(w4[0], x4[0], b4))));
@@ -316,73 +372,80 @@ __global__ __launch_bounds__(256, 2) void chain_head_kernel(const ChainHeadArgs 
         CSTAMP(2 * s + 1);
     }
 
-    // ---- stage 4: Conv1d(64 -> 64, k3, stride 2, pad 1) + bias -> [B,26,64]; rows 4m + q < 26 of each agent ----
+    // ---- stage 4: Conv1d(64 -> 64, k3, stride 2, pad 1) + bias -> [B,26,64] ----
     {
-        typedef Geo<26, 4> GO;
         const ChainStage& st = p.st[4];
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 3 * 4 * 1024, 0x00020000);
         v4f acd[GO::NMT];
 #pragma unroll
         for (int m = 0; m < GO::NMT; ++m) acd[m] = v4f{0.f, 0.f, 0.f, 0.f};
-        // input row of tap 0 = 2 j - 1 (+ 2 halo rows): agent n16 % 4, j = 4 m + n16 / 4
-        kloop<G::KCP, 2 * MSTEP, 64, 3, GO::NMT>(acd, ldsb, ((n16 % 4) * G::ASTR + (1 + 2 * (n16 / 4)) * G::KCP + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        // input row of tap 0 of output row j = 2 j - 1 (+ 2 halo rows): lane i16 is agent i16 % AG, j = RPT m + i16 / AG
+        kloop<G::KCP, 2 * MSTEP, 64, 3, GO::NMT>(acd, ldsb, ((n16 % AG) * G::ASTR + (1 + 2 * (n16 / AG)) * G::KCP + 4 * q) * 4, rsw, lane * 16, 4, wave, wqd);
         CSTAMP(8);
         const float bias = st.bias[n];
         const size_t ybase = (size_t)b0 * 26 * 64;
-        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y + ybase, 0, 4 * 26 * 64 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y + ybase, 0, AG * 26 * 64 * 4, 0x00020000);
 #pragma unroll
-        for (int m = 0; m < GO::NMT; ++m) {
-            if (m == GO::NMT - 1 && 4 * m + q >= 26) continue;
+        for (int m = 0; m < GO::NMT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acd[m][r] + bias), rsy, ((r * 26 + 4 * m + q) * 64 + n) * 4, 0, CLD_STORE_AUX);
-        }
+                if (GO::ok(m, q, r))
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acd[m][r] + bias), rsy,
+                                                          ((GO::agent(q, r) * 26 + GO::pos(m, q, r)) * 64 + n) * 4, 0, CLD_STORE_AUX);
     }
     CSTAMP(9);
     CSTAMP_RT(15);
 }
 
-hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
-    constexpr size_t lds_bytes = sizeof(float) * (kImgFloats + 4 * 52 * 4);
+template <int AG>
+static hipError_t launch_chain_head_inst(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
+    constexpr size_t lds_bytes = sizeof(float) * (img_floats<AG>() + AG * 52 * 4);
     static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups per CU");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel<AG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (b_pad % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chain_head_kernel, dim3(b_pad / 4), dim3(256), lds_bytes, s, a);
+    if (b_pad % AG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_head_kernel<AG>, dim3(b_pad / AG), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
+}
+hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, int agents_per_tile, hipStream_t s) {
+    return agents_per_tile == 1 ? launch_chain_head_inst<1>(a, b_pad, s) : launch_chain_head_inst<4>(a, b_pad, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_conv as one launch
 // ---------------------------------------------------------------------------------------------------------------------
+template <int AG>
 __global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs p) {
-    typedef Geo<26, 4> G;          // stages 0..2 and the transposed conv's input
-    typedef Geo<52, 4> H;          // its output, final_conv
+    typedef Geo<26, AG> G;         // stages 0..2 and the transposed conv's input
+    typedef Geo<52, AG> H;         // its output, final_conv
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const char* ldsb = reinterpret_cast<const char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = blockIdx.x * 4;
+    const int b0 = blockIdx.x * AG;
     const int n = 16 * wave + n16;
 
-    // ---- input rows [4 agents][26][64] -> image (coalesced 256-byte rows) ----
+    // ---- input rows [AG agents][26][64] -> image (coalesced 256-byte rows) ----
     {
+        constexpr int NPC = AG * 26 * 16, NP = (NPC + 255) / 256;
         const v4f* src = reinterpret_cast<const v4f*>(p.x + (size_t)b0 * 26 * 64);
-        v4f st[7];
+        v4f st[NP];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int idx = tid + 256 * i;
-            st[i] = src[idx < 1664 ? idx : tid];
+            st[i] = src[idx < NPC ? idx : tid % NPC];
         }
         zero_halo<G>(lds, tid, 256);
+        for (int i = tid; i < kSlackFloats / 4; i += 256)    // rows behind the L = 26 image: read by the ragged last M-tile, never used (but keep them finite)
+            *reinterpret_cast<v4f*>(lds + G::IMG + i * 4) = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < 1664) {
+            if (idx < NPC) {
                 const int row = idx >> 4, a = row / 26, l = row - a * 26;
                 *reinterpret_cast<v4f*>(lds + a * G::ASTR + (2 + l) * G::KCP + (idx & 15) * 4) = st[i];
             }
@@ -390,34 +453,42 @@ __global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs 
         __syncthreads();
     }
 
-    const int arow = (n16 % 4) * G::ASTR + (n16 / 4) * G::KCP;
-    const int wbase = (2 + q) * G::KCP + n;
-    constexpr int MSTEP = 4 * G::KCP * 4;
-    v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * 7 * 256 + tid;
+    const int arow = G::frag0(n16);
+    const int wbase = (2 + G::row0(q)) * G::KCP + n;
+    constexpr int MSTEP = G::RPT * G::KCP * 4;
+    v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * G::NMT * 256 + tid;
     v4f acc[G::NMT];
+    WQueue<64, 5, G::NMT> wq;
+    WQueue<64, 2, G::NMT> wqe, wqo;
+    WQueue<64, 5, H::NMT> wqf;
+    const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up_even.wfrag), 0, 4 * 2 * 4 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up_odd.wfrag), 0, 4 * 2 * 4 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.fin.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
+    wq.prime(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.st[0].wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000), lane * 16, 4, wave);
 
-    // ---- stages 0..2: Conv1d(64 -> 64, k5) + GroupNorm + Mish at L = 26 (6.5 M-tiles: rows 4 m + q >= 26 of the last one are dummies) ----
+    // ---- stages 0..2: Conv1d(64 -> 64, k5) + GroupNorm + Mish at L = 26 (the last M-tile is ragged: dummy rows masked) ----
 #pragma clang loop unroll(disable)
     for (int s = 0; s < 3; ++s) {
         const ChainStage& st = p.st[s];
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
 #pragma unroll
         for (int m = 0; m < G::NMT; ++m) acc[m] = v4f{0.f, 0.f, 0.f, 0.f};
-        kloop<G::KCP, MSTEP, 64, 5, G::NMT>(acc, ldsb, (arow + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        kloop<G::KCP, MSTEP, 64, 5, G::NMT>(acc, ldsb, (arow + 4 * q) * 4, rsw, lane * 16, 4, wave, wq);
+        if (s < 2) wq.prime(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.st[s + 1].wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000), lane * 16, 4, wave);
+        else wqe.prime(rse, lane * 16, 4, wave);
         float add[4] = {0.f, 0.f, 0.f, 0.f};
         if (st.cb_off >= 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + r) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
+            for (int r = 0; r < 4; ++r) add[r] = p.cbias[(size_t)(b0 + G::agent(q, r)) * p.cb_stride + st.cb_off + n] + (p.tbias ? p.tbias[st.cb_off + n] : 0.f);
         }
         gn_mish<G>(acc, st.bias[n], st.gamma[n], st.beta[n], add, q);
         if (st.res_kind == CHAIN_RES_TENSOR) {
-            const float* rp = st.res + ((size_t)b0 * 26 + q) * 64 + n;
+            const float* rp = st.res + (size_t)b0 * 26 * 64 + n;
 #pragma unroll
-            for (int m = 0; m < G::NMT; ++m) {
-                if (m == G::NMT - 1 && 4 * m + q >= 26) continue;
+            for (int m = 0; m < G::NMT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[m][r] += rp[(r * 26 + 4 * m) * 64];
-            }
+                for (int r = 0; r < 4; ++r)
+                    if (G::ok(m, q, r)) acc[m][r] += rp[(G::agent(q, r) * 26 + G::pos(m, q, r)) * 64];
         } else if (st.res_kind == CHAIN_RES_KEPT) {
 #pragma unroll
             for (int m = 0; m < G::NMT; ++m) {
@@ -441,55 +512,54 @@ __global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs 
         v4f ae[G::NMT], ao[G::NMT];
 #pragma unroll
         for (int m = 0; m < G::NMT; ++m) { ae[m] = v4f{0.f, 0.f, 0.f, 0.f}; ao[m] = v4f{0.f, 0.f, 0.f, 0.f}; }
-        const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up_even.wfrag), 0, 4 * 2 * 4 * 1024, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.up_odd.wfrag), 0, 4 * 2 * 4 * 1024, 0x00020000);
-        kloop<G::KCP, MSTEP, 64, 2, G::NMT>(ae, ldsb, (arow + 1 * G::KCP + 4 * q) * 4, rse, lane * 16, 4, wave);    // tap 0 reads x[j - 1] = image row 2 + j - 1
-        kloop<G::KCP, MSTEP, 64, 2, G::NMT>(ao, ldsb, (arow + 2 * G::KCP + 4 * q) * 4, rso, lane * 16, 4, wave);    // tap 0 reads x[j]
+        wqo.prime(rso, lane * 16, 4, wave);
+        kloop<G::KCP, MSTEP, 64, 2, G::NMT>(ae, ldsb, (arow + 1 * G::KCP + 4 * q) * 4, rse, lane * 16, 4, wave, wqe);    // tap 0 reads x[j - 1] = image row 2 + j - 1
+        wqf.prime(rsf, lane * 16, 4, wave);
+        kloop<G::KCP, MSTEP, 64, 2, G::NMT>(ao, ldsb, (arow + 2 * G::KCP + 4 * q) * 4, rso, lane * 16, 4, wave, wqo);    // tap 0 reads x[j]
         const float be = p.up_even.bias[n], bo = p.up_odd.bias[n];
         __syncthreads();                                 // the L = 26 image is dead
         zero_halo<H>(lds, tid, 256);
-        const int wb = (2 + 2 * q) * H::KCP + n;         // (agent 0, row 2 (0 + q), channel n)
 #pragma unroll
-        for (int m = 0; m < G::NMT; ++m) {
-            if (m == G::NMT - 1 && 4 * m + q >= 26) continue;
+        for (int m = 0; m < G::NMT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                lds[wb + r * H::ASTR + 8 * m * H::KCP] = ae[m][r] + be;
-                lds[wb + r * H::ASTR + (8 * m + 1) * H::KCP] = ao[m][r] + bo;
+                if (!G::ok(m, q, r)) continue;
+                float* o = lds + G::agent(q, r) * H::ASTR + (2 + 2 * G::pos(m, q, r)) * H::KCP + n;
+                o[0] = ae[m][r] + be;
+                o[H::KCP] = ao[m][r] + bo;
             }
-        }
         __syncthreads();
     }
 
     // ---- final_conv.0: Conv1d(64 -> 64, k5) + GroupNorm + Mish at L = 52 ----
-    const int hrow = (n16 % 4) * H::ASTR + (n16 / 4) * H::KCP;
-    constexpr int HSTEP = 4 * H::KCP * 4;
+    const int hrow = H::frag0(n16);
+    constexpr int HSTEP = H::RPT * H::KCP * 4;
     {
         v4f af[H::NMT];
 #pragma unroll
         for (int m = 0; m < H::NMT; ++m) af[m] = v4f{0.f, 0.f, 0.f, 0.f};
-        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.fin.wfrag), 0, 4 * 5 * 4 * 1024, 0x00020000);
-        kloop<H::KCP, HSTEP, 64, 5, H::NMT>(af, ldsb, (hrow + 4 * q) * 4, rsw, lane * 16, 4, wave);
+        kloop<H::KCP, HSTEP, 64, 5, H::NMT>(af, ldsb, (hrow + 4 * q) * 4, rsf, lane * 16, 4, wave, wqf);
         const float add[4] = {0.f, 0.f, 0.f, 0.f};
         gn_mish<H>(af, p.fin.bias[n], p.fin.gamma[n], p.fin.beta[n], add, q);
         __syncthreads();
-        to_image<H>(af, lds, (2 + q) * H::KCP + n, q);
+        to_image<H>(af, lds, (2 + H::row0(q)) * H::KCP + n, q);
         __syncthreads();
     }
 
-    // ---- final_conv.1: Conv1d(64 -> 4, k1): one N tile (4 of its 16 columns real); wave w takes M-tiles w, w + 4, w + 8 (, 12) ----
+    // ---- final_conv.1: Conv1d(64 -> 4, k1): one N tile (4 of its 16 columns real); wave w takes M-tiles w, w + 4, ... ----
     {
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.head_wfrag), 0, 4 * 1024, 0x00020000);
         v4f bw[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[g] = bload16(rsw, lane * 16, g * 1024);
         const int ab = (hrow + 2 * H::KCP + 4 * q) * 4 + wave * HSTEP;       // the centre tap: image row 2 + j
-        v4f ah[4];
+        constexpr int NMI = (H::NMT + 3) / 4;
+        v4f ah[NMI];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) ah[mi] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int mi = 0; mi < NMI; ++mi) ah[mi] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            if (mi == 3 && wave != 0) continue;          // M-tile 12 is wave 0's
+        for (int mi = 0; mi < NMI; ++mi) {
+            if (wave + 4 * mi >= H::NMT) continue;       // (wave-uniform)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4f a4 = *reinterpret_cast<const v4f*>(ldsb + ab + mi * 4 * HSTEP + g * 64);
@@ -500,27 +570,34 @@ __global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs 
         if (n16 < 4) {
             const float hb = p.head_b[n16];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                if (mi == 3 && wave != 0) continue;
-                const int pos = 4 * (wave + 4 * mi) + q;
+            for (int mi = 0; mi < NMI; ++mi) {
+                const int m = wave + 4 * mi;
+                if (m >= H::NMT) continue;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p.eps[((size_t)(b0 + r) * 52 + pos) * 4 + n16] = ah[mi][r] + hb;
+                for (int r = 0; r < 4; ++r) {
+                    const int pos = AG == 4 ? 4 * m + q : 16 * m + 4 * q + r;      // H::pos with a run-time M-tile
+                    if (pos < 52) p.eps[((size_t)(b0 + H::agent(q, r)) * 52 + pos) * 4 + n16] = ah[mi][r] + hb;
+                }
             }
         }
     }
 }
 
-hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, hipStream_t s) {
-    constexpr size_t lds_bytes = sizeof(float) * kImgFloats;
+template <int AG>
+static hipError_t launch_chain_tail_inst(const ChainTailArgs& a, int b_pad, hipStream_t s) {
+    constexpr size_t lds_bytes = sizeof(float) * img_floats<AG>();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_tail_kernel<AG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (b_pad % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chain_tail_kernel, dim3(b_pad / 4), dim3(256), lds_bytes, s, a);
+    if (b_pad % AG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_tail_kernel<AG>, dim3(b_pad / AG), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
+}
+hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile, hipStream_t s) {
+    return agents_per_tile == 1 ? launch_chain_tail_inst<1>(a, b_pad, s) : launch_chain_tail_inst<4>(a, b_pad, s);
 }
 
 }  // namespace cld

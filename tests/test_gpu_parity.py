@@ -68,11 +68,19 @@ def test_unet_forward_golden(golden, tag, eng_default, eng_jitter):
     x = torch.from_numpy(synth.normal(meta["in_seed"], "unet_x", (B, 52, 4))) * 3.0
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
     for r, t in enumerate(meta["t"]):
+        # one launch per layer: every layer's output exists in the workspace (the layer chains a batch of this size takes by
+        # default keep the 64-channel levels in LDS and leave the noise prediction where final_conv.0's activations were)
+        e.force_kernel("unet", "layers")
         eps = e.unet_forward(x, cond, t).cpu().numpy()
         # intermediate activations of row r (taps recorded with per-row timesteps)
         for name, idx, C, L in (("downs_1_1", 4, 128, 26), ("downs_2_1", 5, 256, 13), ("final_conv_0", 7, 64, 52)):
             got = _buf(e, B, idx, C, L)[r]
             assert np.abs(got - g["tap_" + name][r]).max() <= 2e-5, (name, t)
+        assert np.abs(eps[r] - g["eps"][r]).max() <= 2e-5, t
+        e.force_kernel("unet", "auto")
+        eps = e.unet_forward(x, cond, t).cpu().numpy()
+        for name, idx, C, L in (("downs_1_1", 4, 128, 26), ("downs_2_1", 5, 256, 13)):       # the taps that exist either way
+            assert np.abs(_buf(e, B, idx, C, L)[r] - g["tap_" + name][r]).max() <= 2e-5, (name, t)
         assert np.abs(eps[r] - g["eps"][r]).max() <= 2e-5, t
 
 
