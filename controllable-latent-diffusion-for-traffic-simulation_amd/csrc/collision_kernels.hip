@@ -3,10 +3,14 @@
 // left to caller torch code (a host round trip per denoising step).
 //
 // Upstream builds, for every (sample, step), the B x B x 25 table of disk-centre distances of ALL agent pairs of the batch and
-// masks it down to the pairs of one scene.  Here a workgroup owns one (scene, sample): the world poses of the scene's agents at
-// all 52 steps sit in LDS (16 B per pose), one thread per (agent, step) walks the other agents of ITS scene only, rejects far
-// pairs on the centre distance (exact: a disk centre lies within length / 2 - radius of the agent's centre), and evaluates the
-// 25 disk pairs of the rest.  The value and the gradient come out of the same pass: the loss is
+// masks it down to the pairs of one scene.  Here a workgroup owns four agents of one (scene, sample): the world poses of ALL the
+// scene's agents at all 52 steps sit in its LDS (16 B per pose; every workgroup of the scene re-derives them from the plans --
+// 3,328 sincos / atan2 for a 64-agent scene, far cheaper than a second launch), one thread per (own agent, step) walks the other
+// agents of the scene, rejects far pairs on the centre distance (exact: a disk centre lies within length / 2 - radius of the
+// agent's centre) and evaluates the 25 disk pairs of the rest; an agent's 52 per-step sums stay inside one workgroup, so its
+// value is added up in a fixed order (deterministic, no atomics).  A 64-agent scene is 16 workgroups, BASELINE configs[2]'s 32
+// scenes 512: the first form of this kernel (one workgroup per scene) took 880 us there.  Value and gradient come out of the
+// same pass: the loss is
 //     value[i] = [moving_i] sum_t w_t (1 / B) sum_j pen_ij(t),  pen = 1 - d_ij / (r_i + r_j + buffer)  where d_ij <= that bound,
 //     total    = sum_scenes weight_s * mean over the scene's guided agents (and samples) of value   (DiffuserGuidance, :2143-2172),
 // pen is symmetric in (i, j), agents that are stationary or not guided are detached (:512-534), so
@@ -20,6 +24,7 @@ namespace cld {
 namespace {
 constexpr int TT = 52;
 constexpr int kMaxDisks = 8;
+constexpr int kOwn = 4;                    // agents whose (agent, step) items one workgroup evaluates: 4 x 52 = 208 of its 256 threads
 
 // torch.linspace(-e, e, D)[a] as ATen computes it: from the start below the midpoint, from the end above it (init_disks, :481-492)
 __device__ __forceinline__ float disk_centre(float e, int a, int D) {
@@ -32,10 +37,12 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int s = blockIdx.x / p.num_samp, n = blockIdx.x % p.num_samp;
     const int a0 = p.scene_start[s], A = p.scene_start[s + 1] - a0;
+    const int i0 = blockIdx.y * kOwn;                               // this workgroup's agents: i0 .. i0 + kOwn - 1 of the scene
+    if (i0 >= A) return;
     const int tid = threadIdx.x;
     float4* pose = reinterpret_cast<float4*>(lds);                 // [A][52]: world x, y, cos / sin of the world heading
-    float* part = lds + (size_t)A * TT * 4;                        // [A][52]: sum_j pen_ij(t) (weighted) -> per-agent values
-    float* agent = part + (size_t)A * TT;                          // [A][4]: radius, half extent of the disk centres, row-active flag, unused
+    float* part = lds + (size_t)A * TT * 4;                        // [kOwn][52]: sum_j pen_ij(t) (weighted) of the own agents -> their values
+    float* agent = part + (size_t)kOwn * TT;                       // [A][4]: radius, half extent of the disk centres, row-active flag, moving flag
     int& n_guided = *reinterpret_cast<int*>(agent + (size_t)A * 4);   // (in the dynamic allocation: a static __shared__ next to a 160-KB dynamic request is refused)
     const float wgt = p.scene_weight ? p.scene_weight[s] : 1.0f;
 
@@ -75,8 +82,9 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
     const float inv_b = 1.0f / (float)p.B_agents;
     const float coef = (n_guided > 0 && wgt != 0.f) ? wgt / ((float)n_guided * (float)p.num_samp * (float)p.B_agents) : 0.f;
 
-    for (int it = tid; it < A * TT; it += 256) {
-        const int i = it / TT, t = it - i * TT, b = a0 + i;
+    const int own = (A - i0 < kOwn ? A - i0 : kOwn) * TT;
+    for (int io = tid; io < own; io += 256) {
+        const int i = i0 + io / TT, t = io % TT, b = a0 + i, it = i * TT + t;
         const float4 pi = pose[it];
         const float ri = agent[i * 4 + 0], ei = agent[i * 4 + 1], acti = agent[i * 4 + 2];
         const float wt = powf(p.decay_rate, (float)t) / wsum;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
                 }
             }
         }
-        part[it] = pen_sum * wt * inv_b;
+        part[io] = pen_sum * wt * inv_b;
         if (p.grad) {
             float* g = p.grad + ((size_t)(b * p.num_samp + n) * TT + t) * 6;
             const float* gi = p.grad_in ? p.grad_in + ((size_t)(b * p.num_samp + n) * TT + t) * 6 : nullptr;
@@ -134,9 +142,10 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
     }
     __syncthreads();
     if (p.loss) {
-        for (int i = tid; i < A; i += 256) {
+        for (int io = tid; io < own / TT; io += 256) {
+            const int i = i0 + io;
             float v = 0.f;
-            for (int t = 0; t < TT; ++t) v += part[i * TT + t];    // fixed order: deterministic
+            for (int t = 0; t < TT; ++t) v += part[io * TT + t];   // fixed order: deterministic
             p.loss[(size_t)(a0 + i) * p.num_samp + n] = agent[i * 4 + 3] != 0.f ? v : 0.f;
         }
     }
@@ -145,15 +154,15 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
 
 hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, hipStream_t s) {
     if (a.num_disks < 1 || a.num_disks > kMaxDisks || a.num_scenes < 1 || a.num_samp < 1) return hipErrorInvalidValue;
-    const size_t lds_bytes = ((size_t)max_scene_agents * TT * 5 + (size_t)max_scene_agents * 4 + 4) * sizeof(float);
-    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;          // a scene of more than ~150 agents: not built
+    const size_t lds_bytes = ((size_t)max_scene_agents * TT * 4 + (size_t)kOwn * TT + (size_t)max_scene_agents * 4 + 4) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;          // a scene of more than ~190 agents: not built
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agent_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(agent_collision_kernel, dim3(a.num_scenes * a.num_samp), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(agent_collision_kernel, dim3(a.num_scenes * a.num_samp, (max_scene_agents + kOwn - 1) / kOwn), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 
