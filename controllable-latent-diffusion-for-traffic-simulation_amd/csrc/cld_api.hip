@@ -41,7 +41,9 @@ struct ConvLayer {
 
 struct ResBlock { ConvLayer c0, c1, res; bool has_res = false; };
 constexpr long kProfStride = 10;
-constexpr int kChainSmall = 256;      // launch sets of at most this many rows take the one-agent chain tiles (use_chains / chain_tile)
+constexpr int kChainSmall = 944;      // launch sets of at most this many rows take the one-agent chain tiles (chain_tile): measured per U-Net
+                                      // evaluation, one- vs four-agent tiles: 245 / 320 us at 64 rows, 630 / 676 at 512, 916 / 928 at 768,
+                                      // 1,120 / 1,096 at 1,008, 1,081 / 1,052 at 1,024, 2,004 / 1,939 at 2,048
 const char* const kResnet = "context_encoder.map_encoder.encoder_heads.map_model.";
 
 }  // namespace
@@ -462,18 +464,24 @@ hipError_t run_args(cld_handle h, const ConvLayer& l, ConvArgs a, int b_pad, hip
     return launch_maybe_timed(h, l, g, a, b_pad, s);
 }
 
-// The 64-channel levels as LDS-resident layer chains (conv_chain.hip): exact-fp32 handles only; by default from the batch size
-// at which a chain launch (4 agents per workgroup) fills the chip's workgroup slots.
+// The 64-channel levels as LDS-resident layer chains (conv_chain.hip): exact-fp32 handles only (the split-precision mode keeps
+// one launch per layer).
 bool use_chains(cld_handle h, int b_pad) {
     if (h->precision != CLD_PRECISION_F32) return false;
     const int f = h->force_kernel[CLD_KERNEL_UNET];
     if (f == CLD_FORM_LAYERS) return false;
-    if (f == CLD_FORM_CHAIN) return true;
-    return b_pad >= 1024 || b_pad <= kChainSmall;
+    if (f == CLD_FORM_CHAIN || f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4) return true;
+    (void)b_pad;
+    return true;              // measured faster than one launch per layer at every batch size (profiles/r03/chain_check.txt)
 }
 // agents per chain workgroup: 4 (13 M-tiles per wave at L = 52: the throughput tile) or, for the small batches whose time is
 // the LENGTH of the dependent launch sequence, 1 (a quarter of the serial MFMA chain per stage, four times the workgroups)
-int chain_tile(cld_handle, int b_pad) { return b_pad <= kChainSmall ? 1 : 4; }
+int chain_tile(cld_handle h, int b_pad) {
+    const int f = h->force_kernel[CLD_KERNEL_UNET];
+    if (f == CLD_FORM_CHAIN_TILE1) return 1;
+    if (f == CLD_FORM_CHAIN_TILE4) return 4;
+    return b_pad <= kChainSmall ? 1 : 4;
+}
 
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
 // final_conv.0 activations [b_pad,52,64] in w.buf[7].
@@ -672,7 +680,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 3 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : 2)) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 3 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 4 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }

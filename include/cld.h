@@ -418,7 +418,9 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 16x16x4 MFMA tiles */
 #define CLD_FORM_MFMA_QUAD 3  /* guide only: 8 agents per workgroup on the 16-block 4x4x1 fp32 MFMA (the form 2,048 agents run in) */
 #define CLD_FORM_LAYERS 1     /* CLD_KERNEL_UNET only */
-#define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only */
+#define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only: chains, tile (4 agents | 1 agent per workgroup) by batch size */
+#define CLD_FORM_CHAIN_TILE1 3   /* CLD_KERNEL_UNET only: chains with one-agent tiles  */
+#define CLD_FORM_CHAIN_TILE4 4   /* CLD_KERNEL_UNET only: chains with four-agent tiles */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);
 
 /* CLD_PRECISION_* the handle runs with. */

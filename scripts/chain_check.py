@@ -14,7 +14,7 @@ for B in sizes:
     x = torch.randn(B, 52, 4, device="cuda", generator=g) * 2.0
     c = torch.randn(B, 256, device="cuda", generator=g)
     out, ms = {}, {}
-    for form in ("layers", "chain"):
+    for form in ("layers", "chain", "chain1", "chain4"):
         e.force_kernel("unet", form)
         out[form] = e.unet_forward(x, c, 37).clone()
         for _ in range(3):
@@ -37,4 +37,5 @@ for B in sizes:
     print(f"B={B}: CFG step max|chain - layers| = {ds:.3e} (max|x'| = {stp['layers'].abs().max().item():.3e})")
     d = (out["chain"] - out["layers"]).abs().max().item()
     print(f"B={B}: max|chain - layers| = {d:.3e} (max|eps| = {out['layers'].abs().max().item():.3e}, finite={torch.isfinite(out['chain']).all().item()});"
-          f" per evaluation incl. pack / cond-bias / head: layers {ms['layers']*1e3:.1f} us, chain {ms['chain']*1e3:.1f} us", flush=True)
+          f" per evaluation incl. pack / cond-bias / head: layers {ms['layers']*1e3:.1f} us, chain {ms['chain']*1e3:.1f} us"
+          f" (one-agent tiles {ms['chain1']*1e3:.1f}, four-agent tiles {ms['chain4']*1e3:.1f})", flush=True)

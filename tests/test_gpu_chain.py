@@ -1,5 +1,6 @@
 """GPU parity of the layer chains (csrc/conv_chain.hip): the 64-channel levels of a U-Net evaluation as two launches whose tiles
-stay in LDS from layer to layer (exact-fp32 handles; taken by default from 1,024 rows per launch set).  Same bars as
+stay in LDS from layer to layer (exact-fp32 handles; the default at every batch size: one-agent tiles up to 944 rows per launch
+set, four-agent tiles above).  Same bars as
 tests/test_gpu_parity.py: every case is run with the chains forced on at sizes the golden fixtures and the oracle cover, and the
 automatic choice is checked at a launch size that takes it.
 """
@@ -124,8 +125,8 @@ def test_chains_cfg_golden(golden):
     assert torch.equal(a, b)           # w = 0 reproduces the plain chain bit for bit (a tile's result does not depend on the batch around it)
 
 
-@pytest.mark.parametrize("B", [1024, 2100])
-def test_chains_are_the_default_from_1024_rows_and_agree_with_the_layer_launches(B):
+@pytest.mark.parametrize("B", [600, 1024, 2100])
+def test_chains_are_the_default_and_agree_with_the_layer_launches(B):
     from oracle import cld_oracle as O
     e = _engine(100, True, "auto")
     g = torch.Generator().manual_seed(B)
@@ -139,6 +140,12 @@ def test_chains_are_the_default_from_1024_rows_and_agree_with_the_layer_launches
     assert torch.equal(auto, forced)
     assert not torch.equal(auto, layers)             # two different kernels ran (their GroupNorm sums associate differently)
     assert float((auto - layers).abs().max()) <= 1e-5
+    tiles = {}
+    for form in ("chain1", "chain4"):                # one- and four-agent tiles of the same chains (the batch size picks one)
+        e.force_kernel("unet", form)
+        tiles[form] = e.unet_forward(x, cond, 41).clone()
+    assert torch.equal(auto, tiles["chain1" if B <= 944 else "chain4"])
+    assert float((tiles["chain1"] - tiles["chain4"]).abs().max()) <= 1e-5
     rows = torch.tensor([0, 3, 4, B // 2 + 1, B - 2, B - 1])      # first / last tiles of the launch, both sides of a tile boundary
     ref = O.unet_forward(O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), x[rows], cond[rows],
                          torch.full((len(rows),), 41, dtype=torch.long))
