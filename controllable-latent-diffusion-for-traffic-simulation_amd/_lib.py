@@ -46,7 +46,8 @@ class CldGuidance(C.Structure):
                 ("apply_output", C.c_int32), ("no_intermediate", C.c_int32),
                 ("final_lr", C.c_float), ("final_perturb_th", C.c_float), ("final_optimizer", C.c_int32),
                 ("grad_steps", C.c_int32), ("final_grad_steps", C.c_int32), ("guide_clean", C.c_int32),
-                ("collision", C.c_void_p)]        # const cld_collision*
+                ("collision", C.c_void_p),        # const cld_collision*
+                ("map_collision", C.c_void_p)]    # const cld_map_collision*
 
 
 class CldCollision(C.Structure):
@@ -55,6 +56,14 @@ class CldCollision(C.Structure):
                 ("scene_start", C.c_void_p), ("scene_weight", C.c_void_p), ("guided", C.c_void_p),
                 ("num_scenes", C.c_int32), ("num_samp", C.c_int32), ("num_disks", C.c_int32), ("max_scene_agents", C.c_int32),
                 ("buffer_dist", C.c_float), ("decay_rate", C.c_float), ("moving_speed_th", C.c_float)]
+
+
+class CldMapCollision(C.Structure):
+    """include/cld.h `cld_map_collision` (upstream's MapCollisionLoss configured per scene, device pointers)."""
+    _fields_ = [("extent", C.c_void_p), ("raster_from_agent", C.c_void_p), ("drivable_map", C.c_void_p), ("curr_speed", C.c_void_p),
+                ("scene_start", C.c_void_p), ("scene_weight", C.c_void_p),
+                ("num_scenes", C.c_int32), ("num_samp", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("num_points_l", C.c_int32), ("num_points_w", C.c_int32), ("decay_rate", C.c_float), ("moving_speed_th", C.c_float)]
 
 
 _P = C.c_void_p
@@ -92,6 +101,7 @@ SIGNATURES = {
     "cld_compute_reward": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P, _P,
                                      C.c_int32, _P]),
     "cld_agent_collision": (C.c_int, [_P, _P, C.POINTER(CldCollision), _P, _P, _P, C.c_int32, _P]),
+    "cld_map_collision_loss": (C.c_int, [_P, _P, C.POINTER(CldMapCollision), _P, _P, _P, C.c_int32, _P]),
     "cld_world_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "cld_profile_enable": (C.c_int, [_P, C.c_int32]),
     "cld_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -1199,12 +1199,34 @@ static int check_collision(cld_handle h, const char* fn, const cld_collision* c,
     return CLD_OK;
 }
 
+static int check_map_collision(cld_handle h, const char* fn, const cld_map_collision* c, int B) {
+    if (!c->extent || !c->raster_from_agent || !c->drivable_map || !c->curr_speed || !c->scene_start)
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": map collision term: null pointer");
+    if (c->num_scenes < 1 || c->num_samp < 1 || B % c->num_samp || c->H < 1 || c->W < 1)
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": map collision term: B must be agents x num_samp, a map of H x W >= 1");
+    if (c->num_points_l < 1 || c->num_points_w < 1 || c->num_points_l * c->num_points_w > 256)
+        return fail(h, CLD_ERR_ARG, std::string(fn) + ": map collision term: 1..256 sample points per box");
+    return CLD_OK;
+}
+static MapCollisionArgs map_args(const cld_map_collision* c, const float* traj, const float* grad_in, float* loss, float* grad) {
+    MapCollisionArgs a{};
+    a.traj = traj; a.extent = c->extent; a.raster_from_agent = c->raster_from_agent; a.drivable_map = c->drivable_map;
+    a.curr_speed = c->curr_speed; a.scene_start = c->scene_start; a.scene_weight = c->scene_weight; a.grad_in = grad_in;
+    a.loss = loss; a.grad = grad; a.num_scenes = c->num_scenes; a.num_samp = c->num_samp; a.H = c->H; a.W = c->W;
+    a.num_points_l = c->num_points_l; a.num_points_w = c->num_points_w; a.decay_rate = c->decay_rate; a.moving_speed_th = c->moving_speed_th;
+    return a;
+}
+
 static int check_guidance(cld_handle h, const char* fn, const cld_guidance* gd, int B) {
     if (!h->has_decoder) return fail(h, CLD_ERR_STATE, std::string(fn) + ": guidance needs the decoder weights");
-    if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad && !gd->collision))
+    if (!gd->curr_states || (!gd->target_speed && !gd->speed_limit_scale && !gd->acc_limit_scale && !gd->target_pos_scale && !gd->ext_grad && !gd->collision && !gd->map_collision))
         return fail(h, CLD_ERR_ARG, std::string(fn) + ": guidance needs curr_states and at least one loss term");
     if (gd->collision) {
         const int rcc = check_collision(h, fn, gd->collision, B);
+        if (rcc) return rcc;
+    }
+    if (gd->map_collision) {
+        const int rcc = check_map_collision(h, fn, gd->map_collision, B);
         if (rcc) return rcc;
     }
     if (gd->grad_steps < 0 || gd->final_grad_steps < 0 || gd->grad_steps > 64 || gd->final_grad_steps > 64)
@@ -1241,15 +1263,20 @@ static int run_guidance(cld_handle h, const Ws& w, const cld_guidance* gd, int B
         const bool last = k == steps;
         g.opt_step = k;
         g.mean = k == 1 ? mean0 : w.gcur;
+        if (gd->collision || gd->map_collision)      // the scene / map terms are functions of the decoded plans of the current iterate
+            HIPCK(h, launch_decode(h->dec, h->dyn, g.mean, cond, gd->curr_states, nullptr, w.col_traj, B, 1, s, h->force_kernel[CLD_KERNEL_DECODE]));
         if (gd->collision) {
             const cld_collision* c = gd->collision;
-            HIPCK(h, launch_decode(h->dec, h->dyn, g.mean, cond, gd->curr_states, nullptr, w.col_traj, B, 1, s, h->force_kernel[CLD_KERNEL_DECODE]));
             CollisionArgs ca{};
             ca.traj = w.col_traj; ca.extent = c->extent; ca.world_from_agent = c->world_from_agent; ca.curr_speed = c->curr_speed;
             ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.grad_in = gd->ext_grad;
             ca.grad = w.col_grad; ca.B_agents = B / c->num_samp; ca.num_scenes = c->num_scenes; ca.num_samp = c->num_samp;
             ca.num_disks = c->num_disks; ca.buffer_dist = c->buffer_dist; ca.decay_rate = c->decay_rate; ca.moving_speed_th = c->moving_speed_th;
             HIPCK(h, launch_agent_collision(ca, c->max_scene_agents, s));
+            g.ext_grad = w.col_grad;
+        }
+        if (gd->map_collision) {                     // adds to whatever gradient is there already (caller's ext_grad, agent collisions)
+            HIPCK(h, launch_map_collision(map_args(gd->map_collision, w.col_traj, gd->collision ? w.col_grad : gd->ext_grad, nullptr, w.col_grad), B, s));
             g.ext_grad = w.col_grad;
         }
         g.z = last ? z : nullptr;
@@ -1587,6 +1614,16 @@ int cld_agent_collision(cld_handle h, const float* traj, const cld_collision* c,
     ca.loss = loss; ca.grad = grad; ca.B_agents = B / c->num_samp; ca.num_scenes = c->num_scenes; ca.num_samp = c->num_samp;
     ca.num_disks = c->num_disks; ca.buffer_dist = c->buffer_dist; ca.decay_rate = c->decay_rate; ca.moving_speed_th = c->moving_speed_th;
     HIPCK(h, launch_agent_collision(ca, c->max_scene_agents, static_cast<hipStream_t>(stream)));
+    return CLD_OK;
+}
+
+int cld_map_collision_loss(cld_handle h, const float* traj, const cld_map_collision* c, const float* grad_in, float* loss,
+                           float* grad, int32_t B, void* stream) {
+    if (!h) return CLD_ERR_ARG;
+    if (!traj || !c || B < 1 || (!loss && !grad)) return fail(h, CLD_ERR_ARG, "cld_map_collision_loss: bad argument");
+    int rc = check_map_collision(h, "cld_map_collision_loss", c, B);
+    if (rc) return rc;
+    HIPCK(h, launch_map_collision(map_args(c, traj, grad_in, loss, grad), B, static_cast<hipStream_t>(stream)));
     return CLD_OK;
 }
 

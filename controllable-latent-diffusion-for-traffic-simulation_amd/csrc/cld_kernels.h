@@ -288,6 +288,23 @@ struct CollisionArgs {
 };
 hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, hipStream_t s);
 
+// upstream's MapCollisionLoss + its gradient w.r.t. the decoded plans (collision_kernels.hip; guidance_loss.py:717-875)
+struct MapCollisionArgs {
+    const float* traj;               // [rows = B_agents * num_samp, 52, 6]
+    const float* extent;             // [B_agents, 3]
+    const float* raster_from_agent;  // [B_agents, 3, 3]
+    const unsigned char* drivable_map;   // [B_agents, H, W], != 0 = drivable
+    const float* curr_speed;         // [B_agents]
+    const int* scene_start;          // [num_scenes + 1]
+    const float* scene_weight;       // [num_scenes] or null
+    const float* grad_in;            // [rows, 52, 6] or null (may alias grad)
+    float* loss;                     // [rows] or null
+    float* grad;                     // [rows, 52, 6] or null
+    int num_scenes, num_samp, H, W, num_points_l, num_points_w;
+    float decay_rate, moving_speed_th;
+};
+hipError_t launch_map_collision(const MapCollisionArgs& a, int rows, hipStream_t s);
+
 // PPO reward (models/rl/criticmodel.py:7-64)
 struct RewardArgs {
     const float* traj;                // [B,52,6] descaled (x, y, v, yaw, acc, yaw-rate), agent frame

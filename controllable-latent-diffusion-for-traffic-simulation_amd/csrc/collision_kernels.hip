@@ -166,4 +166,135 @@ hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// MapCollisionLoss (src/tbsim/utils/guidance_loss.py:717-875): agents should not leave the drivable area
+// ---------------------------------------------------------------------------------------------------------------------
+// One workgroup per plan (agent x sample), one wave per time step (13 steps each): the num_points_lw grid of sample points of
+// the agent's box at that step's pose (:731-753) goes to LDS with its off-road flag (drivable map at the truncated, clamped
+// raster pixel, :797-805); steps where some but not all points are off road (:807-809) then give every off-road point
+// 1 - (distance to the nearest ON-road point of the box) / (box diagonal), with the on-road point carrying the gradient and the
+// off-road one detached (:833-848) -- which makes d / d pose = -(p_i - p_j) / (d diag) applied at p_i = pos + R(yaw) loc_i.
+// Upstream takes the distances from torch.cdist (its matrix-multiply path at 100 points: ~1e-4 m of rounding at these
+// coordinates, which also enters its backward); here they are exact differences, so values agree to rounding and gradients to
+// the reference's own ~0.3 % noise.
+namespace {
+constexpr int kMaxPts = 256;
+
+__device__ __forceinline__ float unit_linspace(int a, int n) {      // torch.linspace(-0.5, 0.5, n)[a]
+    if (n <= 1) return -0.5f;
+    const float step = 1.0f / (float)(n - 1);
+    return a < n / 2 ? -0.5f + step * (float)a : 0.5f - step * (float)(n - 1 - a);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void map_collision_kernel(const MapCollisionArgs p) {
+    __shared__ float4 pts[4][kMaxPts];                  // per wave: x, y (agent frame), off-road flag
+    __shared__ float part[TT];
+    __shared__ float s_coef;
+    const int row = blockIdx.x, b = row / p.num_samp;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = p.num_points_l * p.num_points_w;
+    if (tid == 0) {                                     // the agent's scene: weight / (agents of the scene x samples)
+        float c = 0.f;
+        for (int s = 0; s < p.num_scenes; ++s)
+            if (b >= p.scene_start[s] && b < p.scene_start[s + 1]) {
+                const float w = p.scene_weight ? p.scene_weight[s] : 1.0f;
+                c = w / ((float)(p.scene_start[s + 1] - p.scene_start[s]) * (float)p.num_samp);
+            }
+        s_coef = c;
+    }
+    __syncthreads();
+    const bool moving = fabsf(p.curr_speed[b]) > p.moving_speed_th;
+    const float len = p.extent[b * 3 + 0], wid = p.extent[b * 3 + 1];
+    const float inv_diag = 1.0f / sqrtf(len * len + wid * wid);
+    const float* R = p.raster_from_agent + (size_t)b * 9;
+    const unsigned char* dm = p.drivable_map + (size_t)b * p.H * p.W;
+    float wsum = 0.f, wp = 1.f;
+    for (int t = 0; t < TT; ++t) { wsum += wp; wp *= p.decay_rate; }
+    for (int t = wave; t < TT; t += 4) {
+        const float* x = p.traj + ((size_t)row * TT + t) * 6;
+        const float px = x[0], py = x[1];
+        float sy, cy;
+        sincosf(x[3], &sy, &cy);
+        int n_off = 0;
+        for (int k = lane; k < P; k += 64) {
+            const float lx = unit_linspace(k / p.num_points_w, p.num_points_l) * len, wy = unit_linspace(k % p.num_points_w, p.num_points_w) * wid;
+            const float ax = lx * cy - wy * sy + px, ay = lx * sy + wy * cy + py;
+            int ix = (int)(R[0] * ax + R[1] * ay + R[2]), iy = (int)(R[3] * ax + R[4] * ay + R[5]);      // .long(): truncation toward zero
+            ix = min(max(ix, 0), p.W - 1); iy = min(max(iy, 0), p.H - 1);
+            const bool off = dm[(size_t)iy * p.W + ix] == 0;
+            pts[wave][k] = make_float4(ax, ay, off ? 1.f : 0.f, 0.f);
+            n_off += off ? 1 : 0;
+        }
+        n_off = (int)wave_sum((float)n_off);
+        __syncthreads();                                // (every wave runs the same 13 iterations) the points are visible to all lanes
+        float loss = 0.f, gx = 0.f, gy = 0.f, gyaw = 0.f;
+        if (n_off != 0 && n_off != P && moving) {
+            for (int j = lane; j < P; j += 64) {
+                const float4 pj = pts[wave][j];
+                if (pj.z == 0.f) continue;
+                // nearest on-road point.  On a regular grid mirror-image candidates are equidistant in exact arithmetic (an isolated
+                // off-road sample between two on-road neighbours): torch.amin's backward shares the gradient evenly among the minima
+                // it finds equal, which for mirror images cancels the translation part.  Candidates within 1e-5 (relative, squared
+                // distance) of the minimum are treated as that tie -- the symmetric choice, instead of whichever rounding favours.
+                float best = 3.0e38f;
+                for (int i = 0; i < P; ++i) {
+                    const float4 pi = pts[wave][i];
+                    if (pi.z != 0.f) continue;
+                    const float ex = pi.x - pj.x, ey = pi.y - pj.y;
+                    best = fminf(best, ex * ex + ey * ey);
+                }
+                const float lim = best * (1.0f + 1e-5f);
+                float sx = 0.f, sy = 0.f, sw = 0.f, cnt = 0.f;
+                for (int i = 0; i < P; ++i) {
+                    const float4 pi = pts[wave][i];
+                    if (pi.z != 0.f) continue;
+                    const float ex = pi.x - pj.x, ey = pi.y - pj.y;
+                    if (ex * ex + ey * ey <= lim) {
+                        sx += ex; sy += ey; cnt += 1.f;
+                        sw += -ex * (pi.y - py) + ey * (pi.x - px);        // d p_i / d yaw = perp(p_i - pos)
+                    }
+                }
+                const float d = sqrtf(best);
+                loss += 1.0f - d * inv_diag;
+                if (d > 0.f) {
+                    const float k = -inv_diag / (d * cnt);
+                    gx += k * sx; gy += k * sy; gyaw += k * sw;
+                }
+            }
+        }
+        loss = wave_sum(loss); gx = wave_sum(gx); gy = wave_sum(gy); gyaw = wave_sum(gyaw);
+        __syncthreads();                                // nobody still reads the points the next step overwrites
+        const float wt = powf(p.decay_rate, (float)t) / wsum;
+        if (lane == 0) {
+            part[t] = loss * wt;
+            if (p.grad) {
+                float* g = p.grad + ((size_t)row * TT + t) * 6;
+                const float* gi = p.grad_in ? p.grad_in + ((size_t)row * TT + t) * 6 : nullptr;
+                const float sc = s_coef * wt;
+                const float o[6] = {sc * gx, sc * gy, 0.f, sc * gyaw, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 6; ++k) g[k] = o[k] + (gi ? gi[k] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && p.loss) {
+        float v = 0.f;
+        for (int t = 0; t < TT; ++t) v += part[t];      // fixed order: deterministic
+        p.loss[row] = v;
+    }
+}
+}  // namespace
+
+hipError_t launch_map_collision(const MapCollisionArgs& a, int rows, hipStream_t s) {
+    if (a.num_points_l < 1 || a.num_points_w < 1 || a.num_points_l * a.num_points_w > kMaxPts || a.num_samp < 1 || rows < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(map_collision_kernel, dim3(rows), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace cld

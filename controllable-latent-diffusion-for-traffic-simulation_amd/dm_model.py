@@ -58,8 +58,9 @@ def repeat_guidance(guidance: Mapping, num_samp: int, curr_states=None) -> dict:
     for k in ("speed_limit", "acc_limit", "target_pos"):
         if g.get(k) is not None:
             g[k] = tuple(rep(v) for v in g[k])
-    if g.get("agent_collision") is not None:        # per-AGENT tensors stay as they are: sample n of every agent lives in scene copy n
-        g["agent_collision"] = dict(g["agent_collision"], num_samp=num_samp)
+    for k in ("agent_collision", "map_collision"):  # per-AGENT tensors stay as they are: sample n of every agent lives in scene copy n
+        if g.get(k) is not None:
+            g[k] = dict(g[k], num_samp=num_samp)
     return g
 
 

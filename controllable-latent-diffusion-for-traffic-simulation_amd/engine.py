@@ -215,7 +215,7 @@ class Engine:
     def _guidance(self, g: Mapping, B: int):
         """dict(curr_states [B,4], target_speed [B,52] | None, loss_scale [B] | None, speed_limit (limit, scale) | None,
         acc_limit (limit, scale) | None, target_pos (pos [B,2], time index [B], scale) | None, lr | None, perturb_th | None | "sigma", optimizer "adam" | "sgd",
-        grad_steps = 1, guide_clean = False, agent_collision: dict | None (see _collision))
+        grad_steps = 1, guide_clean = False, agent_collision: dict | None (see _collision), map_collision: dict | None (see _map_collision))
         -> (CldGuidance, tensors kept alive).  A `scale` is a per-agent tensor [B] (weight / (agents of the scene * 52),
         as DiffuserGuidance averages) or a scalar weight (divided by 52 here).  lr None = sigma_t; perturb_th None = no clip (what
         the reference's perturb() does), "sigma" = clip to sigma_t, a number = clip to it (include/cld.h)."""
@@ -253,9 +253,11 @@ class Engine:
         if fopt not in _lib.OPTIMIZERS:
             raise CldError(f"unknown guidance optimizer '{fopt}' (adam | sgd)")
         fth = (fo or {}).get("perturb_th", None)       # None = no clip: what upstream's perturb() does (guidance_loss.py:2237,2273-2276)
-        col = ckeep = None
+        col = ckeep = mcol = mkeep = None
         if g.get("agent_collision") is not None:
             col, ckeep = self._collision(g["agent_collision"], B)
+        if g.get("map_collision") is not None:
+            mcol, mkeep = self._map_collision(g["map_collision"], B)
         cg = _lib.CldGuidance(cs.data_ptr(), None if ts is None else ts.data_ptr(), None if ls is None else ls.data_ptr(),
                               float(g["lr"]) if g.get("lr") else 0.0,
                               -1.0 if th is None else (0.0 if th == "sigma" else float(th)), _lib.OPTIMIZERS[opt],
@@ -266,8 +268,8 @@ class Engine:
                               float((fo or {}).get("lr", 0.3) or 0.0),
                               -1.0 if fth is None else (0.0 if fth == "sigma" else float(fth)), _lib.OPTIMIZERS[fopt],
                               int(g.get("grad_steps", 1) or 1), int((fo or {}).get("grad_steps", 1) or 1), 1 if g.get("guide_clean") else 0,
-                              None if col is None else C.addressof(col))
-        return cg, (cs, ts, ls, sls, als, tp, tt, tps, eg, col, ckeep)
+                              None if col is None else C.addressof(col), None if mcol is None else C.addressof(mcol))
+        return cg, (cs, ts, ls, sls, als, tp, tt, tps, eg, col, ckeep, mcol, mkeep)
 
     def _collision(self, c: Mapping, B: int):
         """dict(extent [A,3], world_from_agent [A,3,3], curr_speed [A], scene_index [A] (consecutive blocks) | scene_sizes,
@@ -307,6 +309,58 @@ class Engine:
                                None if guided is None else guided.data_ptr(), S, N, int(c.get("num_disks", 5)), max(sizes),
                                float(c.get("buffer_dist", 0.2)), float(c.get("decay_rate", 0.9)), float(c.get("guide_moving_speed_th", 0.5)))
         return cc, (ext, wfa, spd, start, wts, guided)
+
+    def _scene_blocks(self, c: Mapping, A: int, what: str):
+        """-> (scene sizes, start offsets on the device, per-scene weights on the device) of a scene-structured loss config."""
+        if c.get("scene_sizes") is not None:
+            sizes = [int(v) for v in c["scene_sizes"]]
+        elif c.get("scene_index") is not None:
+            _, counts = torch.unique_consecutive(torch.as_tensor(c["scene_index"]).cpu(), return_counts=True)
+            sizes = [int(v) for v in counts]
+        else:
+            sizes = [A]
+        if sum(sizes) != A or min(sizes) < 1:
+            raise CldError(f"{what}: scene sizes {sizes} do not cover the {A} agents")
+        start = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=self.device)
+        wv = c.get("weight", 1.0)
+        wts = torch.full((len(sizes),), float(wv), device=self.device) if np.isscalar(wv) else self._f32(torch.as_tensor(wv, dtype=torch.float32), (len(sizes),))
+        return sizes, start, wts
+
+    def _map_collision(self, c: Mapping, B: int):
+        """dict(extent [A,3], raster_from_agent [A,3,3], drivable_map [A,H,W] (non-zero = drivable), curr_speed [A], scene_index |
+        scene_sizes (default: one scene), weight: scalar or per-scene sequence, num_samp = 1, num_points_lw = (10, 10),
+        decay_rate = 0.9, guide_moving_speed_th = 0.5) -> (CldMapCollision, tensors kept alive): upstream's MapCollisionLoss
+        (src/tbsim/utils/guidance_loss.py:717-875)."""
+        N = int(c.get("num_samp", 1))
+        if B % N:
+            raise CldError(f"map_collision: {B} rows are not a multiple of num_samp = {N}")
+        A = B // N
+        ext = self._f32(c["extent"], (A, 3)); rfa = self._f32(c["raster_from_agent"], (A, 3, 3)); spd = self._f32(c["curr_speed"], (A,))
+        dm = torch.as_tensor(c["drivable_map"])
+        if dm.dim() != 3 or dm.shape[0] != A:
+            raise CldError(f"map_collision: drivable_map must be [{A},H,W], got {tuple(dm.shape)}")
+        dm = (dm != 0).to(self.device, torch.uint8).contiguous()
+        sizes, start, wts = self._scene_blocks(c, A, "map_collision")
+        nl, nw = (int(v) for v in c.get("num_points_lw", (10, 10)))
+        cc = _lib.CldMapCollision(ext.data_ptr(), rfa.data_ptr(), dm.data_ptr(), spd.data_ptr(), start.data_ptr(), wts.data_ptr(),
+                                  len(sizes), N, int(dm.shape[1]), int(dm.shape[2]), nl, nw, float(c.get("decay_rate", 0.9)),
+                                  float(c.get("guide_moving_speed_th", 0.5)))
+        return cc, (ext, rfa, dm, spd, start, wts)
+
+    def map_collision(self, traj, cfg: Mapping, grad_in=None, want_grad=True):
+        """Upstream's MapCollisionLoss on decoded plans [B,52,6] (descaled, sample-minor rows) -> (per-plan values [B],
+        d total / d traj [B,52,6]); cld_map_collision_loss."""
+        traj = self._f32(traj)
+        B = traj.shape[0]
+        traj = self._f32(traj, (B, T, 6))
+        cc, keep = self._map_collision(cfg, B)
+        gi = None if grad_in is None else self._f32(grad_in, (B, T, 6))
+        loss = torch.empty(B, dtype=torch.float32, device=self.device)
+        grad = torch.empty(B, T, 6, dtype=torch.float32, device=self.device) if want_grad else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.cld_map_collision_loss(self._h, _ptr(traj), C.byref(cc), _ptr(gi), _ptr(loss), _ptr(grad), B, self._stream()),
+                        "cld_map_collision_loss")
+        return (loss, grad) if want_grad else loss
 
     def agent_collision(self, traj, collision: Mapping, grad_in=None, want_grad=True):
         """Upstream's AgentCollisionLoss on decoded plans [B,52,6] (descaled, sample-minor rows) -> (per-agent values [B] as

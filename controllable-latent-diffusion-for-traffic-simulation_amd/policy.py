@@ -130,9 +130,11 @@ class CldPolicy:
         vals = (self.vae.engine.guidance_losses(traj.reshape(B * N, 52, 6), g).reshape(B, N, 4) if has_builtin
                 else torch.full((B, N, 4), float("nan"), device=traj.device))
         nan = torch.full((B, N), float("nan"), device=vals.device)
-        colv = None
+        colv = mapv = None
         if g.get("agent_collision") is not None:     # per-agent values as upstream files them (unweighted; :2166-2168)
             colv = self.vae.engine.agent_collision(traj.reshape(B * N, 52, 6), dict(g["agent_collision"], num_samp=N), want_grad=False).reshape(B, N)
+        if g.get("map_collision") is not None:
+            mapv = self.vae.engine.map_collision(traj.reshape(B * N, 52, 6), dict(g["map_collision"], num_samp=N), want_grad=False).reshape(B, N)
         out, names = {}, []
         if from_cfg:
             cfg_list, scene_index = self._guidance_cfg
@@ -145,7 +147,7 @@ class CldPolicy:
                     mask = torch.zeros(B, dtype=torch.bool)
                     mask[idx] = True
                     mask = mask.to(vals.device)
-                    v = colv if c["name"] == "agent_collision" else vals[..., LOSS_COLUMN[c["name"]]]
+                    v = colv if c["name"] == "agent_collision" else (mapv if c["name"] == "map_collision" else vals[..., LOSS_COLUMN[c["name"]]])
                     out["%s_scene_%03d_%02d" % (c["name"], si, gi)] = torch.where(mask[:, None], v, nan)
         else:       # a plain `guidance=` dict: one scene, one entry per active term
             names.append([])
@@ -156,6 +158,9 @@ class CldPolicy:
             if colv is not None:
                 out["agent_collision_scene_000_%02d" % len(names[0])] = colv
                 names[0].append("agent_collision")
+            if mapv is not None:
+                out["map_collision_scene_000_%02d" % len(names[0])] = mapv
+                names[0].append("map_collision")
         return out, names
 
     @torch.no_grad()
@@ -269,10 +274,10 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, d
     `{'name', 'weight', 'params', 'agents'}` dicts; `scene_index [B]` maps agents to scenes (consecutive runs).  Each loss
     is averaged over the agents it applies to within its scene and multiplied by its weight; that is folded into the
     per-agent scales of the kernel: weight / (agents * horizon) for the per-step losses, weight / agents for the waypoint
-    losses.  Supported names: target_speed, speed_limit, acc_limit, target_pos_at_time, target_pos, and agent_collision (needs
+    losses.  Supported names: target_speed, speed_limit, acc_limit, target_pos_at_time, target_pos, agent_collision (needs
     `data_batch` with `extent`, `world_from_agent`, `curr_speed`: the observation fields upstream's loss reads,
-    guidance_loss.py:506-510; at most one per scene, one parameter set per call); the others (map collision, social groups, stop
-    signs, ...) sample the raster or are not built.  One speed / acceleration limit value per call."""
+    guidance_loss.py:506-510) and map_collision (`extent`, `raster_from_agent`, `drivable_map`, `curr_speed`, :773-775); at most
+    one of each per scene, one parameter set per call; the others (social groups, stop signs, lane keeping, ...) are not built.  One speed / acceleration limit value per call."""
     scene_index = torch.as_tensor(scene_index).reshape(-1).cpu()
     B = scene_index.numel()
     _, local = torch.unique_consecutive(scene_index, return_inverse=True)
@@ -282,7 +287,7 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, d
     ts_scale = torch.zeros(B); ts = torch.zeros(B, horizon); has_ts = False
     sl_scale = torch.zeros(B); al_scale = torch.zeros(B); sl = al = None
     tp = torch.zeros(B, 2); tt = torch.zeros(B, dtype=torch.int32); tp_scale = torch.zeros(B); has_tp = False
-    col = None
+    col = mcol = None
     for si, cfgs in enumerate(guidance_config_list):
         members = torch.nonzero(local == si).reshape(-1)
         for cfg in cfgs:
@@ -334,9 +339,25 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, d
                 col["weight"][si] = wgt
                 if agents is not None:
                     col["agents"][si] = list(agents)
+            elif name == "map_collision":
+                need = ("extent", "raster_from_agent", "drivable_map", "curr_speed")
+                if data_batch is None or any(k not in data_batch for k in need):
+                    raise ValueError("map_collision needs data_batch with extent, raster_from_agent, drivable_map and curr_speed")
+                if agents is not None:
+                    raise NotImplementedError("map_collision on an `agents` subset (upstream itself cannot run it: guidance_loss.py:857-859)")
+                S = int(local.max()) + 1
+                key = (tuple(int(v) for v in prm.get("num_points_lw", (10, 10))), float(prm.get("decay_rate", 0.9)), float(prm.get("guide_moving_speed_th", 0.5)))
+                if mcol is None:
+                    mcol = dict({k: data_batch[k] for k in need}, scene_index=scene_index, weight=[0.0] * S, num_points_lw=key[0], decay_rate=key[1],
+                                guide_moving_speed_th=key[2])
+                elif (tuple(mcol["num_points_lw"]), mcol["decay_rate"], mcol["guide_moving_speed_th"]) != key:
+                    raise ValueError("one map_collision parameter set per call")
+                if mcol["weight"][si] != 0.0:
+                    raise ValueError("two map_collision losses on one scene")
+                mcol["weight"][si] = wgt
             else:
                 raise NotImplementedError(f"guidance loss '{name}' is not built (target_speed, speed_limit, acc_limit, "
-                                          f"target_pos_at_time, target_pos, agent_collision are)")
+                                          f"target_pos_at_time, target_pos, agent_collision, map_collision are)")
     if has_ts:
         out["target_speed"], out["loss_scale"] = ts, ts_scale
     if sl is not None:
@@ -348,6 +369,8 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, d
     if col is not None:
         col["agents"] = col["agents"] or None
         out["agent_collision"] = col
+    if mcol is not None:
+        out["map_collision"] = mcol
     if not out:
         raise ValueError("no guidance loss configured")
     return out

@@ -291,6 +291,38 @@ def make_collision_trajectories(B: int, N: int, curr_speed, seed: int = 1) -> np
     return np.stack((x, y, v, yaw, acc, yr), axis=-1).astype(np.float32)
 
 
+def make_map_scene(B: int, seed: int = 1, half_width_m=(1.6, 3.5)) -> dict:
+    """Synthetic inputs of upstream's MapCollisionLoss (src/tbsim/utils/guidance_loss.py:717-875): raster_from_agent [B,3,3]
+    (2 px/m, the agent at pixel (56, 112), a small rotation: trajdata_utils.py:380-389), a drivable map [B,224,224] that is a
+    straight road band of a per-agent half width along the agent's heading (so that a 2-m-wide agent with some lateral offset
+    hangs over the kerb for part of its plan), extents and speeds."""
+    th = uniform(seed, "map_rot", (B,), -0.2, 0.2).astype(np.float64)
+    R = np.zeros((B, 3, 3), np.float64)
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1] = 2 * np.cos(th), -2 * np.sin(th), 2 * np.sin(th), 2 * np.cos(th)
+    R[:, 0, 2], R[:, 1, 2], R[:, 2, 2] = 56.0, 112.0, 1.0
+    hw = uniform(seed, "map_halfwidth", (B,), half_width_m[0], half_width_m[1]).astype(np.float64)
+    yy, xx = np.meshgrid(np.arange(224), np.arange(224), indexing="ij")
+    dmap = np.zeros((B, 224, 224), bool)
+    for b in range(B):                       # pixel -> agent frame: p = R^-1 (pix - t); drivable where |p_y| < half width
+        Ri = np.linalg.inv(R[b, :2, :2])
+        py = Ri[1, 0] * (xx - 56.0) + Ri[1, 1] * (yy - 112.0)
+        dmap[b] = np.abs(py) < hw[b]
+    ext = np.stack([uniform(seed, "map_len", (B,), 3.8, 5.2), uniform(seed, "map_wid", (B,), 1.7, 2.2), np.full((B,), 1.6, np.float32)], axis=1)
+    speed = uniform(seed, "map_speed", (B,), 1.0, 12.0)
+    speed[::4] = 0.2
+    return {"raster_from_agent": R.astype(np.float32), "drivable_map": dmap, "extent": ext.astype(np.float32), "curr_speed": speed.astype(np.float32)}
+
+
+def make_map_trajectories(B: int, N: int, curr_speed, seed: int = 1) -> np.ndarray:
+    """[B,N,52,6] plans that drive forward with a lateral drift of up to a couple of metres (across the kerb of make_map_scene)."""
+    tr = make_collision_trajectories(B, N, curr_speed, seed)
+    drift = uniform(seed, "mapt_drift", (B, N, 1), -0.06, 0.06) * np.arange(HORIZON, dtype=np.float32)[None, None, :]
+    off = uniform(seed, "mapt_off", (B, N, 1), -1.2, 1.2)
+    tr[..., 1] += off + drift
+    tr[..., 3] += uniform(seed, "mapt_yaw", (B, N, 1), -0.15, 0.15)
+    return tr.astype(np.float32)
+
+
 def make_future(B: int, seed: int = 1) -> dict:
     """Synthetic ground-truth futures for the encoder path: a unicycle roll-out with smooth random controls in
     the agent frame -> target_positions [B,52,2], target_yaws [B,52,1], curr_speed [B]."""

@@ -230,6 +230,8 @@ typedef struct cld_guidance {
      * to the step as ext_grad (added to a caller ext_grad).  NULL = no such term.  Counts as a loss term for the
      * "at least one term" rule. */
     const struct cld_collision* collision;
+    /* MapCollisionLoss (guidance_loss.py:717-875) as a term, same mechanics (cld_map_collision_loss).  NULL = none. */
+    const struct cld_map_collision* map_collision;
 } cld_guidance;
 
 /* Upstream's AgentCollisionLoss (src/tbsim/utils/guidance_loss.py:442-630) as configured through DiffuserGuidance
@@ -261,6 +263,33 @@ typedef struct cld_collision {
  * Either output may be NULL. */
 int cld_agent_collision(cld_handle h, const float* traj, const cld_collision* c, const float* grad_in, float* loss, float* grad,
                         int32_t B, void* stream);
+
+/* Upstream's MapCollisionLoss (src/tbsim/utils/guidance_loss.py:717-875): the agent's box is sampled on a num_points_l x
+ * num_points_w grid at every step of the plan; a sample is off road where the drivable map is 0 at its raster pixel (truncated,
+ * clamped); steps where some but not all samples are off road contribute, per off-road sample, 1 - (distance to the nearest
+ * on-road sample) / (box diagonal); steps weighted by decay_rate^t (normalised); agents slower than moving_speed_th contribute
+ * nothing.  total = sum over scenes of scene_weight[s] * mean over the scene's agents (x samples) -- upstream itself can only
+ * run this loss on a single-scene batch without an `agents` subset (it indexes the full-batch speeds with the masked batch size,
+ * :857-859); scenes here are independent, which is the evident intent.  Rows of traj are sample-minor as in cld_collision. */
+typedef struct cld_map_collision {
+    const float* extent;             /* DEVICE [A,3]                                           */
+    const float* raster_from_agent;  /* DEVICE [A,3,3] row-major                               */
+    const uint8_t* drivable_map;     /* DEVICE [A,H,W], non-zero = drivable                    */
+    const float* curr_speed;         /* DEVICE [A]                                             */
+    const int32_t* scene_start;      /* DEVICE [num_scenes + 1]                                */
+    const float* scene_weight;       /* DEVICE [num_scenes], 0 = scene not guided              */
+    int32_t num_scenes;
+    int32_t num_samp;
+    int32_t H, W;
+    int32_t num_points_l, num_points_w;   /* upstream default (10, 10); product <= 256         */
+    float decay_rate;                /* 0.9                                                    */
+    float moving_speed_th;           /* 0.5                                                    */
+} cld_map_collision;
+
+/* traj [B,52,6] descaled -> loss [B] (per-plan values, as upstream files them) and grad [B,52,6] = d total / d traj
+ * (+ grad_in when given; grad_in may be grad itself).  Either output may be NULL. */
+int cld_map_collision_loss(cld_handle h, const float* traj, const cld_map_collision* c, const float* grad_in, float* loss,
+                           float* grad, int32_t B, void* stream);
 
 /* cld_sample (non_cond == NULL) / cld_sample_cfg (non_cond != NULL) with the guidance step above inside the loop. */
 int cld_sample_guided(cld_handle h, const float* x_T, const float* noise, const float* cond, const float* non_cond,

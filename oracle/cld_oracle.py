@@ -424,7 +424,7 @@ def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, tap
 # --------------------------------------------------------------------------- #
 def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Optional[Tensor], loss_scale: Optional[Tensor],
                   lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None, target_pos=None,
-                  collision: Optional[dict] = None, grad_steps: int = 1, num_samp: int = 1):
+                  collision: Optional[dict] = None, grad_steps: int = 1, num_samp: int = 1, map_collision: Optional[dict] = None):
     """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282) with decoder = `decode` and
     TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target| (+ optional SpeedLimitLoss / AccLimitLoss
     terms, each a (limit, per-agent scale) pair; + `collision`: the agent_collision configs, see scene_collision_total).
@@ -457,6 +457,8 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
                     loss = loss + (F.softmin(dist, dim=-1) * (e ** 2).sum(dim=-1)).mean() * s_[bb]
         if collision is not None:
             loss = loss + scene_collision_total(traj, collision, num_samp)
+        if map_collision is not None:
+            loss = loss + scene_map_collision_total(traj, map_collision, num_samp)
         return loss
 
     x = mean.clone()
@@ -618,6 +620,63 @@ def agent_collision_loss(x: Tensor, extent: Tensor, world_from_agent: Tensor, cu
     out = (pen * wts.view(T_, 1, 1, 1)).sum(0).mean(-1).transpose(0, 1)                  # [B,N]
     out = torch.where(moving.view(B, 1), out, torch.zeros_like(out))
     return out if agt_mask is None else out[agt_mask]
+
+
+def map_collision_loss(x: Tensor, extent: Tensor, raster_from_agent: Tensor, drivable_map: Tensor, curr_speed: Tensor,
+                       num_points_lw=(10, 10), decay_rate: float = 0.9, moving_speed_th: float = 0.5) -> Tensor:
+    """MapCollisionLoss.forward (src/tbsim/utils/guidance_loss.py:772-875) on x [B,N,T,6] -> [B,N].  Every agent box is sampled
+    on a num_points_lw grid (:731-735, scaled by length / width, rotated and shifted by the plan's pose, :745-753); a point is
+    off road where the drivable map is 0 at its raster pixel (coordinates truncated toward zero and clamped to the map,
+    :797-805; metrics.py:451-481).  Only steps where SOME but not all points are off road count (:807-809); there every off-road
+    point contributes 1 - (distance to the nearest on-road point of the box) / (box diagonal), the on-road points carrying the
+    gradient and the off-road ones detached (:833-848).  Steps are weighted by decay_rate ** t (normalised) and summed; agents
+    slower than moving_speed_th contribute nothing."""
+    B, N, T_, _ = x.shape
+    lw = extent[:, :2]
+    lwise, wwise = torch.linspace(-0.5, 0.5, num_points_lw[0]), torch.linspace(-0.5, 0.5, num_points_lw[1])
+    loc = torch.cartesian_prod(lwise, wwise).to(x.dtype)                     # [P,2]
+    P = loc.shape[0]
+    locs = loc[None] * lw[:, None, :]                                        # [B,P,2]
+    yaw, pos = x[..., 3], x[..., :2]
+    c, s_ = torch.cos(yaw)[..., None], torch.sin(yaw)[..., None]             # [B,N,T,1]
+    lx, wy = locs[:, None, None, :, 0], locs[:, None, None, :, 1]            # [B,1,1,P]
+    pts = torch.stack([lx * c - wy * s_, lx * s_ + wy * c], dim=-1) + pos[..., None, :]     # [B,N,T,P,2] agent frame
+    Rm, tv = raster_from_agent[:, None, None, None, :2, :2], raster_from_agent[:, None, None, None, :2, 2]
+    pix = ((Rm @ pts.unsqueeze(-1)).squeeze(-1) + tv).long()                 # truncation, as .long() does
+    H, W = drivable_map.shape[-2:]
+    px, py = pix[..., 0].clamp(0, W - 1), pix[..., 1].clamp(0, H - 1)
+    bi = torch.arange(B).view(B, 1, 1, 1).expand(B, N, T_, P)
+    off = ~(drivable_map[bi, py, px] != 0)                                   # [B,N,T,P]
+    cnt = off.sum(dim=-1)
+    overlap = (cnt != 0) & (cnt != P)
+    diag = (lw * lw).sum(dim=-1).sqrt()
+    d = (pts[..., :, None, :] - pts.detach()[..., None, :, :]).norm(dim=-1)   # rows carry the gradient, columns detached
+    d = torch.where(off[..., :, None], torch.full_like(d, float("inf")), d)  # rows of off-road points masked out
+    dmin = d.amin(dim=-2)                                                    # over the rows: nearest on-road point of every column
+    per_pt = torch.where(off & overlap[..., None], 1.0 - dmin / diag.view(B, 1, 1, 1), torch.zeros_like(dmin))
+    per_step = per_pt.sum(dim=-1)
+    moving = curr_speed.abs() > moving_speed_th
+    per_step = torch.where(moving.view(B, 1, 1), per_step, torch.zeros_like(per_step))
+    wts = torch.tensor([decay_rate ** t for t in range(T_)], dtype=x.dtype)
+    wts = wts / wts.sum()
+    return (per_step * wts).sum(dim=-1)
+
+
+def scene_map_collision_total(traj: Tensor, mp: dict, num_samp: int = 1) -> Tensor:
+    """What DiffuserGuidance.compute_guidance_loss (guidance_loss.py:2143-2172) adds for `map_collision` configs: sum over scenes
+    of weight * mean over the scene's agents (and samples); mp: extent, raster_from_agent, drivable_map, curr_speed, scene_index,
+    scene_weight [S] and the loss parameters."""
+    BN = traj.shape[0]
+    B = BN // num_samp
+    x = traj.reshape(B, num_samp, traj.shape[1], 6)
+    _, local = torch.unique_consecutive(mp["scene_index"], return_inverse=True)
+    kw = {k: mp[k] for k in ("num_points_lw", "decay_rate", "moving_speed_th") if k in mp}
+    vals = map_collision_loss(x, mp["extent"], mp["raster_from_agent"], mp["drivable_map"], mp["curr_speed"], **kw)
+    tot = x.sum() * 0.0
+    for si, wgt in enumerate(mp["scene_weight"]):
+        if float(wgt) != 0.0:
+            tot = tot + vals[local == si].mean() * float(wgt)
+    return tot
 
 
 def scene_collision_total(traj: Tensor, col: dict, num_samp: int = 1) -> Tensor:

@@ -533,6 +533,54 @@ def section_guidance_multi(ref):
                             "decoder": "oracle.decode (pinned by decode.npz)"}, **out)
 
 
+def section_map_collision(ref):
+    """Upstream's MapCollisionLoss (src/tbsim/utils/guidance_loss.py:717-875) through DiffuserGuidance (:2143-2172) on a
+    synthetic [B,N,52,6] batch (one scene of 6 agents, 2 samples: with more than one scene in the batch -- or an `agents` subset --
+    the loss indexes the full-batch curr_speed with the masked batch size, :857-859, and cannot run): per-agent values, the
+    weighted total and its autograd gradient; and one perturb() call (SGD) with a map_collision + target_speed configuration,
+    decoder hook = the oracle's decode.  NOTE on the gradient: torch.cdist takes its matrix-multiply path for 100 points
+    (|a|^2 + |b|^2 - 2ab: absolute errors ~1e-4 m at coordinates of tens of metres) and divides by that distance in its
+    backward, so the reference's own gradient carries ~0.3 % of noise relative to the exact expression; the values do not."""
+    with _refimport.redirect_stdout(_refimport.io.StringIO()):
+        import tbsim.utils.guidance_loss as gl
+    from oracle import cld_oracle as O
+    B, N = 6, 2
+    sc = synth.make_map_scene(B, IN_SEED)
+    db = {k: T(v) for k, v in sc.items()}
+    db["drivable_map"] = db["drivable_map"].float()
+    db["scene_index"] = torch.zeros(B, dtype=torch.long)
+    traj = T(synth.make_map_trajectories(B, N, sc["curr_speed"], IN_SEED))
+    g = gl.DiffuserGuidance([[{"name": "map_collision", "weight": 2.0, "params": {"num_points_lw": (10, 10)}, "agents": None}]])
+    x = traj.clone().requires_grad_(True)
+    tot, per = g.compute_guidance_loss(x * 1.0, db)
+    tot.backward()
+    out = {"total": tot.detach().reshape(1), "grad": x.grad.clone(), "values": per["map_collision_scene_000_00"]}
+    # through perturb(): 8 agents, decoded plans; raster / map / extents of make_map_scene(8), curr_speed = curr_states[:, 2]
+    B2 = 8
+    wdec = O.to_torch(synth.make_decoder_weights(W_SEED))
+    inp = synth.make_inputs(B2, IN_SEED)
+    cond, cs = T(inp["cond_feat"]), T(inp["curr_states"])
+    mean = T(synth.normal(IN_SEED, "guide_mean", (B2, 52, 4)))
+    tgt = synth.uniform(IN_SEED, "guide_target_speed", (B2, 52), 0.0, 12.0)
+    sc2 = synth.make_map_scene(B2, IN_SEED + 1, half_width_m=(0.6, 1.4))
+    sc2["curr_speed"] = inp["curr_states"][:, 2].copy()
+    db2 = {k: T(v) for k, v in sc2.items()}
+    db2["drivable_map"] = db2["drivable_map"].float()
+    db2["scene_index"] = torch.zeros(B2, dtype=torch.long)
+    cfg = [[{"name": "map_collision", "weight": 0.5, "params": {"num_points_lw": (10, 10)}, "agents": None},
+            {"name": "target_speed", "weight": 1.0, "params": {"dt": 0.1, "target_speed": tgt, "fut_valid": np.ones((B2, 52), bool)}, "agents": None}]]
+    pg = gl.PerturbationGuidance(transform=lambda x, data_batch, params, bsize, num_samp: x, transform_params=None)
+    pg.set_guidance(cfg)
+    xg, per2 = pg.perturb(mean.clone(), db2, {"optimizer": "sgd", "lr": 20.0, "grad_steps": 1, "perturb_th": None}, num_samp=1,
+                          decoder=lambda x: O.decode(wdec, x, cond, cs, True))
+    out["guided_map_sgd1"] = xg.detach()
+    out["guided_values"] = per2["map_collision_scene_000_00"]
+    save("map_collision", {"B": B, "N": N, "in_seed": IN_SEED, "scene": "synth.make_map_scene(B, in_seed)", "traj": "synth.make_map_trajectories(B, N, curr_speed, in_seed)",
+                           "weight": 2.0, "num_points_lw": [10, 10], "decay_rate": 0.9, "moving_speed_th": 0.5,
+                           "guided": {"B": B2, "scene": "synth.make_map_scene(8, in_seed + 1, half_width_m=(0.6, 1.4)), curr_speed = curr_states[:,2]",
+                                      "map_weight": 0.5, "target_speed_weight": 1.0, "optimizer": "sgd", "lr": 20.0}}, **out)
+
+
 def main():
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
@@ -542,7 +590,8 @@ def main():
         for name in sys.argv[1:]:
             {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride, "losses": section_losses,
              "n50": section_n50, "small": section_small, "log_prob_t0": section_log_prob_t0, "select": section_select, "guide_losses": section_guide_losses,
-             "agent_collision": section_agent_collision, "guidance_multi": section_guidance_multi}[name](ref)
+             "agent_collision": section_agent_collision, "guidance_multi": section_guidance_multi,
+             "map_collision": section_map_collision}[name](ref)
         return
     section_cfg(ref)
     section_encoder(ref)
@@ -558,6 +607,7 @@ def main():
     section_guide_losses(ref)
     section_agent_collision(ref)
     section_guidance_multi(ref)
+    section_map_collision(ref)
 
     # ---- (i) schedule buffers, n = 100 and n = 10 --------------------------------
     for n in (100, 10):

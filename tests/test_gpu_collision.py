@@ -200,3 +200,108 @@ def test_get_action_with_a_collision_config_and_guide_clean():
     assert bool((idx == idx[0]).all()) and int(idx[0]) == int(torch.argmin(ref.sum(dim=0)))
     act2, info2 = pol.get_action(obs, num_action_samples=N, noise=noise, guide_clean=True)
     assert torch.isfinite(info2["trajectories"]).all() and not torch.equal(info2["trajectories"], info["trajectories"])
+
+
+def _map_cfg(db, weight, N=1, sizes=None):
+    c = dict(extent=db["extent"], raster_from_agent=db["raster_from_agent"], drivable_map=db["drivable_map"], curr_speed=db["curr_speed"],
+             weight=weight, num_samp=N)
+    if sizes is not None:
+        c["scene_sizes"] = sizes
+    return c
+
+
+def test_map_collision_kernel_golden(golden, eng):
+    """Upstream's MapCollisionLoss + DiffuserGuidance + autograd: per-plan values to rounding, the gradient to the ~0.3 % of
+    noise the reference's torch.cdist backward carries (fixture generator), and one SGD step through perturb() in every
+    formulation of the guidance kernel."""
+    from tests.test_oracle_golden import map_inputs
+    meta, g = golden("map_collision")
+    B, N = meta["B"], meta["N"]
+    db = map_inputs(B, meta["in_seed"])
+    traj = torch.from_numpy(synth.make_map_trajectories(B, N, db["curr_speed"].numpy(), meta["in_seed"])).reshape(B * N, 52, 6)
+    loss, grad = eng.map_collision(traj, _map_cfg(db, meta["weight"], N))
+    assert np.abs(loss.cpu().numpy().reshape(B, N) - g["values"]).max() <= 2e-5
+    ref = g["grad"].reshape(B * N, 52, 6)
+    assert np.abs(grad.cpu().numpy() - ref).max() <= 1e-2 * np.abs(ref).max()
+    gm = meta["guided"]
+    B2 = gm["B"]
+    inp = synth.make_inputs(B2, meta["in_seed"])
+    db2 = map_inputs(B2, meta["in_seed"] + 1, (0.6, 1.4))
+    db2["curr_speed"] = torch.from_numpy(inp["curr_states"][:, 2].copy())
+    mean = torch.from_numpy(synth.normal(meta["in_seed"], "guide_mean", (B2, 52, 4)))
+    tgt = torch.from_numpy(synth.uniform(meta["in_seed"], "guide_target_speed", (B2, 52), 0.0, 12.0))
+    gd = dict(curr_states=torch.from_numpy(inp["curr_states"]), target_speed=tgt, loss_scale=torch.full((B2,), gm["target_speed_weight"] / (B2 * 52)),
+              lr=gm["lr"], optimizer="sgd", map_collision=_map_cfg(db2, gm["map_weight"]))
+    moved = np.abs(g["guided_map_sgd1"] - mean.numpy()).max()
+    for kernel in ("valu", "mfma", "quad"):
+        eng.force_kernel("guide", kernel)
+        try:
+            xg = eng.guidance_step(mean, torch.from_numpy(inp["cond_feat"]), gd, sigma=0.5)
+        finally:
+            eng.force_kernel("guide", "auto")
+        assert np.abs(xg.cpu().numpy() - g["guided_map_sgd1"]).max() <= 1e-2 * moved, kernel
+
+
+@pytest.mark.parametrize("grid,gtol", [((1, 16), 2e-4), ((14, 1), 0.15), ((12, 6), 0.15)])
+def test_map_collision_kernel_vs_oracle_multi_scene(eng, grid, gtol):
+    """Three scenes (40 + 7 + 30 agents, 2 samples, one scene unguided): values against the oracle to rounding, deterministic,
+    grad_in added.  The gradient is compared tightly on a sample line ACROSS the box (the road is a band along the heading, so every
+    off-road point has one nearest on-road point); along the box and on a two-dimensional grid isolated off-road samples sit between
+    mirror-image on-road neighbours that are equidistant in exact arithmetic: torch shares the gradient among the minima it finds
+    bit-equal and otherwise takes whichever rounding made smaller (the reference's cdist adds 1e-4 m of noise of its own), the kernel
+    shares it among candidates within 1e-5 -- so there the gradients are only required to agree in the large."""
+    from oracle import cld_oracle as O
+    sizes, N = [40, 7, 30], 2
+    B = sum(sizes)
+    sc = synth.make_map_scene(B, 17)
+    db = {k: torch.from_numpy(v) for k, v in sc.items()}
+    db["scene_index"] = torch.repeat_interleave(torch.arange(3), torch.tensor(sizes))
+    traj = torch.from_numpy(synth.make_map_trajectories(B, N, sc["curr_speed"], 17)).reshape(B * N, 52, 6)
+    wts = [1.5, 0.0, 0.7]
+    x = traj.clone().requires_grad_(True)
+    tot = O.scene_map_collision_total(x, dict(db, scene_weight=wts, num_points_lw=grid), N)
+    (gref,) = torch.autograd.grad(tot, x)
+    vref = O.map_collision_loss(traj.reshape(B, N, 52, 6), db["extent"], db["raster_from_agent"], db["drivable_map"], db["curr_speed"], num_points_lw=grid).reshape(-1)
+    cfg = dict(_map_cfg(db, wts, N, sizes), num_points_lw=grid)
+    loss, grad = eng.map_collision(traj, cfg)
+    assert float(vref.max()) > 0.5 and float(gref.abs().max()) > 0.0
+    assert float((loss.cpu() - vref).abs().max()) <= 2e-5 * max(1.0, float(vref.max()))
+    assert float((grad.cpu() - gref).abs().max()) <= gtol * float(gref.abs().max())
+    gin = torch.randn(B * N, 52, 6)
+    _, grad2 = eng.map_collision(traj, cfg, grad_in=gin)
+    assert float((grad2.cpu() - (grad.cpu() + gin)).abs().max()) <= 1e-6
+    assert torch.equal(eng.map_collision(traj, cfg)[1], grad)
+
+
+def test_sampling_step_with_both_collision_terms_vs_oracle(eng):
+    """cld_sample_step with agent_collision + map_collision + target speed in one guided step (two SGD steps) against the oracle."""
+    from oracle import cld_oracle as O
+    sizes = [6, 6]
+    B = sum(sizes)
+    w, wd = O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), O.to_torch(synth.make_decoder_weights(0))
+    inp = synth.make_inputs(B, 21)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    sc = synth.make_collision_scene(sizes, 21)
+    sc["curr_speed"] = inp["curr_states"][:, 2].copy()
+    db = {k: torch.from_numpy(v) for k, v in sc.items()}
+    ms = synth.make_map_scene(B, 23, half_width_m=(0.6, 1.4))
+    mdb = {k: torch.from_numpy(v) for k, v in ms.items()}
+    mdb["curr_speed"], mdb["scene_index"] = db["curr_speed"], db["scene_index"]
+    x_t = torch.from_numpy(synth.normal(21, "xt", (B, 52, 4))) * 0.7
+    z = torch.from_numpy(synth.normal(22, "z", (B, 52, 4)))
+    tgt = torch.from_numpy(synth.uniform(21, "tgt", (B, 52), 0.0, 12.0))
+    scale = torch.full((B,), 1.0 / (6 * 52))
+    sched = O.schedule(100)
+    t = torch.full((B,), 40, dtype=torch.long)
+    mean = sched["x_t_cof"][40] * x_t - sched["noise_cof"][40] * O.unet_forward(w, x_t, cond, t)
+    sigma = float((0.5 * sched["posterior_log_variance_clipped"][40]).exp())
+    ref, _ = O.guidance_step(wd, mean, cond, cs, tgt, scale, 5.0, None, "sgd", collision=dict(db, scene_weight=[40.0, 60.0]),
+                             grad_steps=2, map_collision=dict(mdb, scene_weight=[0.3, 0.2]))
+    got = eng.sample_step(x_t, cond, 40, z=z, guidance=dict(curr_states=cs, target_speed=tgt, loss_scale=scale, lr=5.0, optimizer="sgd", grad_steps=2,
+                          agent_collision=dict(extent=db["extent"], world_from_agent=db["world_from_agent"], curr_speed=db["curr_speed"],
+                                               scene_index=db["scene_index"], weight=[40.0, 60.0]),
+                          map_collision=dict(_map_cfg(mdb, [0.3, 0.2]), scene_index=db["scene_index"])))
+    sc_ = max(1.0, float(mean.abs().max()))
+    assert float((got["mean_guided"].cpu() - ref).abs().max()) <= 2e-4 * sc_
+    assert float((got["x_next"].cpu() - (ref + sigma * z)).abs().max()) <= 2e-4 * sc_
+    assert float((ref - mean).abs().max()) > 1e-3

@@ -181,16 +181,18 @@ def test_guidance_struct_matches_header():
                                           "speed_limit", "acc_limit", "speed_limit_scale", "acc_limit_scale",
                                           "target_pos", "target_time", "target_pos_scale", "ext_grad",
                                           "apply_output", "no_intermediate", "final_lr", "final_perturb_th", "final_optimizer",
-                                          "grad_steps", "final_grad_steps", "guide_clean", "collision"]
-    assert ctypes.sizeof(g) == 136 and g.apply_output.offset == 96 and g.final_optimizer.offset == 112 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
+                                          "grad_steps", "final_grad_steps", "guide_clean", "collision", "map_collision"]
+    assert ctypes.sizeof(g) == 144 and g.apply_output.offset == 96 and g.final_optimizer.offset == 112 and g.lr.offset == 24 and g.optimizer.offset == 32 and g.speed_limit_scale.offset == 48
     assert g.grad_steps.offset == 116 and g.guide_clean.offset == 124 and g.collision.offset == 128      # appended in round 3: the earlier layout is untouched
     c = _lib.CldCollision
     assert [n for n, _ in c._fields_] == ["extent", "world_from_agent", "curr_speed", "scene_start", "scene_weight", "guided", "num_scenes",
                                           "num_samp", "num_disks", "max_scene_agents", "buffer_dist", "decay_rate", "moving_speed_th"]
     assert ctypes.sizeof(c) == 80 and c.num_scenes.offset == 48 and c.buffer_dist.offset == 64
+    m = _lib.CldMapCollision
+    assert ctypes.sizeof(m) == 80 and m.num_scenes.offset == 48 and m.decay_rate.offset == 72
     hdr = open(os.path.join(ROOT, "include", "cld.h")).read()
     body = hdr[hdr.index("typedef struct cld_guidance {"):hdr.index("} cld_guidance;")]
-    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad|apply_output|no_intermediate|final_lr|final_perturb_th|final_optimizer|grad_steps|final_grad_steps|guide_clean|collision);", body)] == [n for n, _ in g._fields_]
+    assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad|apply_output|no_intermediate|final_lr|final_perturb_th|final_optimizer|grad_steps|final_grad_steps|guide_clean|collision|map_collision);", body)] == [n for n, _ in g._fields_]
 
 
 def test_timers_keep_the_reference_surface():
@@ -233,8 +235,10 @@ def test_guidance_config_adapter_matches_the_golden_configurations():
     assert torch.equal(pos[4], torch.tensor([0.0, 1.0])) and torch.equal(pos[6], torch.tensor([2.0, 3.0]))
     with pytest.raises(ValueError):                                          # the loss reads observation fields: they must be handed over
         guidance_from_config([[{"name": "agent_collision", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         guidance_from_config([[{"name": "map_collision", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
+    with pytest.raises(NotImplementedError):
+        guidance_from_config([[{"name": "social_group", "weight": 1.0, "params": {}, "agents": None}], []], scene_index)
     db = {"extent": torch.ones(B, 3), "world_from_agent": torch.eye(3).expand(B, 3, 3), "curr_speed": torch.ones(B)}
     g = guidance_from_config([[{"name": "agent_collision", "weight": 3.0, "params": {"num_disks": 4}, "agents": [0, 2]}],
                               [{"name": "speed_limit", "weight": 3.0, "params": {"speed_limit": 6.0}, "agents": None}]], scene_index, data_batch=db)

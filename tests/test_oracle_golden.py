@@ -505,3 +505,40 @@ def test_guidance_multi_step_and_collision_vs_reference_perturb(golden, case):
     else:
         assert err.max() <= 5e-6
     assert np.abs(g[f"guided_{case}"] - mean.numpy()).max() > 1e-3            # the guidance moved the mean
+
+
+def map_inputs(meta_scene_B, seed, half_width=None):
+    sc = synth.make_map_scene(meta_scene_B, seed) if half_width is None else synth.make_map_scene(meta_scene_B, seed, half_width_m=half_width)
+    db = {k: torch.from_numpy(v) for k, v in sc.items()}
+    db["scene_index"] = torch.zeros(meta_scene_B, dtype=torch.long)
+    return db
+
+
+def test_map_collision_loss_vs_reference(golden):
+    """f-3 widening: upstream's MapCollisionLoss through DiffuserGuidance (make_golden.section_map_collision): values to rounding;
+    the gradient to the ~0.3 % the reference's own torch.cdist backward carries (its matrix-multiply distance path; see the
+    fixture's generator), and through the reference's perturb() with the decoder hook."""
+    meta, g = golden("map_collision")
+    B, N = meta["B"], meta["N"]
+    db = map_inputs(B, meta["in_seed"])
+    traj = torch.from_numpy(synth.make_map_trajectories(B, N, db["curr_speed"].numpy(), meta["in_seed"]))
+    vals = O.map_collision_loss(traj, db["extent"], db["raster_from_agent"], db["drivable_map"], db["curr_speed"])
+    assert np.abs(vals.numpy() - g["values"]).max() <= 1e-5 and float(g["values"].max()) > 1.0
+    x = traj.reshape(B * N, 52, 6).clone().requires_grad_(True)
+    tot = O.scene_map_collision_total(x, dict(db, scene_weight=[meta["weight"]]), N)
+    (grad,) = torch.autograd.grad(tot, x)
+    assert abs(float(tot) - float(g["total"][0])) <= 1e-5
+    assert np.abs(grad.reshape(B, N, 52, 6).numpy() - g["grad"]).max() <= 1e-2 * np.abs(g["grad"]).max()
+    gm = meta["guided"]
+    B2 = gm["B"]
+    inp = synth.make_inputs(B2, meta["in_seed"])
+    db2 = map_inputs(B2, meta["in_seed"] + 1, (0.6, 1.4))
+    db2["curr_speed"] = torch.from_numpy(inp["curr_states"][:, 2].copy())
+    wdec = O.to_torch(synth.make_decoder_weights(0))
+    mean = torch.from_numpy(synth.normal(meta["in_seed"], "guide_mean", (B2, 52, 4)))
+    tgt = torch.from_numpy(synth.uniform(meta["in_seed"], "guide_target_speed", (B2, 52), 0.0, 12.0))
+    scale = torch.full((B2,), gm["target_speed_weight"] / (B2 * 52))
+    xg, _ = O.guidance_step(wdec, mean, torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"]), tgt, scale, gm["lr"], None, "sgd",
+                            map_collision=dict(db2, scene_weight=[gm["map_weight"]]))
+    moved = np.abs(g["guided_map_sgd1"] - mean.numpy()).max()
+    assert np.abs(xg.numpy() - g["guided_map_sgd1"]).max() <= 1e-2 * moved and moved > 1e-3
