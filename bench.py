@@ -371,6 +371,10 @@ def main():
         secondary("f16x2_mode", lambda: sec_workload(
             "configs2", args.steps, 1, precision="f16x2",
             note="optional split-precision mode (--precision f16x2), same workload and parity bars; not the headline"))
+        secondary("one_scene", lambda: sec_workload(
+            "configs1", 5, 2, scenes=1, agents=64,
+            note="ONE 64-agent scene, 100 denoising steps, CFG off: the latency regime (a sample call is a chain of dependent launches; "
+                 "ms_per_step is the latency of a sample + decode)"))
         secondary("configs3_one_gpu", lambda: sec_workload(
             "configs3", 1, 1, note="the N = 1 point of the strong-scaling job that `bench.py --gpus N` runs for N > 1 (65,536 agents on one GPU)"))
         secondary("configs4_one_gpu_shard", lambda: sec_workload(

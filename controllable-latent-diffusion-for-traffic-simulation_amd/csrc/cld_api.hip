@@ -66,6 +66,8 @@ struct cld_handle_s {
     ConvLayer down[2], upT[2][2], final_cb;
     float *wc = nullptr, *cbias_b = nullptr, *tb = nullptr, *head_w = nullptr, *head_b = nullptr, *res4_w = nullptr, *res4_b = nullptr;
     float* head_wfrag = nullptr;        // final_conv.1 as an MFMA N tile (the tail chain of conv_chain.hip)
+    const HeadArgs* fuse_upd = nullptr; // set by the caller of run_unet: a DDPM update the tail chain may apply itself (plain steps, no CFG combine)
+    bool upd_fused = false;             // ... and whether the last run_unet did
     bool eps_in_buf7 = false;           // the last run_unet left the noise prediction [b_pad,52,4] in buf[7] (chains) instead of final_conv.0's activations
     DecoderWeights dec{};
     EncoderWeights enc{};
@@ -553,6 +555,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
                  h->upT[0][1], make_args(h, h->upT[0][1], b[6], nullptr, b[3], nullptr, w.cb, tbr), b_pad, s);   // 128@26
     if (e != hipSuccess) return e;
     h->eps_in_buf7 = false;
+    h->upd_fused = false;
     if (use_chains(h, b_pad)) {
         // ups.1.0's first conv + residual projection as one pair launch (K = 256 x 5 from HBM), then everything behind it --
         // ups.1.0's second conv, ups.1.1, the transposed conv, final_conv.0 and final_conv.1 -- as one launch (conv_chain.hip)
@@ -577,6 +580,13 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ct.head_wfrag = h->head_wfrag; ct.head_b = h->head_b;
         ct.cbias = w.cb; ct.cb_stride = NCB; ct.tbias = tbr;
         ct.keep = b[2]; ct.eps = b[7];
+        h->upd_fused = false;
+        if (const HeadArgs* u = h->fuse_upd) {           // the step's DDPM update in the same launch
+            ct.eps = nullptr;
+            ct.upd_x = u->x; ct.upd_z = u->z; ct.upd_mean_out = u->mean_out; ct.upd_x_out = u->x_out;
+            ct.xc = u->xc; ct.nc = u->nc; ct.sg = u->sg; ct.B = u->B; ct.seed = u->seed; ct.step_salt = u->step_salt;
+            h->upd_fused = true;
+        }
         h->launch_counter += 6;
         e = launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
@@ -1300,17 +1310,11 @@ static int sample_iteration(cld_handle h, const Ws& w, bool cfg, int B, int bp, 
                             float* mean_guided, float* grad, bool want_mean, hipStream_t s) {
     const int bpn = cfg ? 2 * bp : bp;
     float* x_hi = w.xw + (size_t)bp * T * D;
-    HIPCK(h, run_unet(h, w, w.xw, i, bpn, s));
     const float sigma = std::exp(0.5f * h->plvc[i]);
     // upstream defaults: apply_guidance_intermediate on, apply_guidance_output off (diffuser.py:876-881, scene_edit_config.py:84-85)
     const bool guide = gd && (i > 0 ? !gd->no_intermediate : gd->apply_output != 0);
     HeadArgs a{};
-    head_source(h, w, a); a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
-    if (cfg) {
-        if (a.eps_in) a.eps_in_uncond = a.eps_in + (size_t)bp * T * D;
-        else a.f_uncond = w.buf[7] + (size_t)bp * T * 64;
-        a.cfg_w = guidance_w;
-    }
+    a.w = h->head_w; a.b = h->head_b; a.x = w.xw; a.B = B; a.b_pad = bp;
     a.z = z;
     a.seed = seed; a.step_salt = salt;
     a.xc = h->x_t_cof[i]; a.nc = h->noise_cof[i];
@@ -1325,7 +1329,19 @@ static int sample_iteration(cld_handle h, const Ws& w, bool cfg, int B, int bp, 
         a.x_out2 = cfg ? x_hi : nullptr;
         a.mean_out = (i == 0 || want_mean) ? w.meanb : nullptr;
     }
-    HIPCK(h, launch_head(a, s));
+    h->fuse_upd = cfg ? nullptr : &a;                    // without the CFG combine the tail chain applies the update itself
+    const hipError_t eu = run_unet(h, w, w.xw, i, bpn, s);
+    h->fuse_upd = nullptr;
+    HIPCK(h, eu);
+    if (!h->upd_fused) {
+        head_source(h, w, a);
+        if (cfg) {
+            if (a.eps_in) a.eps_in_uncond = a.eps_in + (size_t)bp * T * D;
+            else a.f_uncond = w.buf[7] + (size_t)bp * T * 64;
+            a.cfg_w = guidance_w;
+        }
+        HIPCK(h, launch_head(a, s));
+    }
     if (guide) {
         // a guided t = 0 step (apply_output): x0 IS the guided mean, and log_prob_final is taken around it (w.xtmp), not around the
         // unguided mean it was stepped away from -- sigma_0 = 1e-10 would turn that step into ~ -1e18

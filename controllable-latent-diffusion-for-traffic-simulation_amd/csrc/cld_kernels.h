@@ -114,7 +114,17 @@ struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_c
     int cb_stride;
     const float* tbias;
     float* keep;          // b_pad * 1792 floats of per-thread spill
-    float* eps;           // [b_pad,52,4] noise prediction
+    float* eps;           // [b_pad,52,4] noise prediction, or null when the update below consumes it
+    // the DDPM update on the noise prediction, in the same launch (plain sampling steps: no CFG combine): mean = xc x - nc eps;
+    // x' = mean + sg z (dm_model.py:144-163); upd_x null = off.  upd_x_out may alias upd_x (every element is read, then written,
+    // by one lane).  Rows >= B are padding: no noise.
+    const float* upd_x;   // [b_pad,52,4] the step's input latent
+    const float* upd_z;   // [B,52,4] noise, or null (on-device generator keyed by seed / step_salt)
+    float* upd_mean_out;  // [b_pad,52,4] or null
+    float* upd_x_out;     // [b_pad,52,4] or null
+    float xc, nc, sg;
+    int B;
+    unsigned long long seed, step_salt;
 };
 hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile /* 4 | 1 */, hipStream_t s);
 

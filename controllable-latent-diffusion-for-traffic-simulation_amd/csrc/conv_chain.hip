@@ -576,7 +576,20 @@ __global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int pos = AG == 4 ? 4 * m + q : 16 * m + 4 * q + r;      // H::pos with a run-time M-tile
-                    if (pos < 52) p.eps[((size_t)(b0 + H::agent(q, r)) * 52 + pos) * 4 + n16] = ah[mi][r] + hb;
+                    if (pos >= 52) continue;
+                    const int b = b0 + H::agent(q, r);
+                    const size_t row = (size_t)b * 52 + pos, e = row * 4 + n16;
+                    const float ev = ah[mi][r] + hb;
+                    if (p.eps) p.eps[e] = ev;
+                    if (p.upd_x) {                       // x_{t-1} = x_t_cof x - noise_cof eps + sigma z, as head_kernel writes it
+                        const float mean = p.xc * p.upd_x[e] - p.nc * ev;
+                        if (p.upd_mean_out) p.upd_mean_out[e] = mean;
+                        if (p.upd_x_out) {
+                            float zz = 0.f;
+                            if (p.sg != 0.f && b < p.B) zz = p.upd_z ? p.upd_z[e] : normal4(p.seed, p.step_salt, (unsigned)row)[n16];
+                            p.upd_x_out[e] = mean + p.sg * zz;
+                        }
+                    }
                 }
             }
         }
