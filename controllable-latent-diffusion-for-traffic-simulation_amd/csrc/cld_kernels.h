@@ -66,7 +66,7 @@ struct ConvGeom {
     int padc;     // 1: the input has fewer real channels than one K chunk (the 4-channel latent)
     int ain;      // activation format of the input: 0 = fp32, 1 = S22 (fp16 hi/lo planes, split-precision loop)
     int aout;     // activation format of the output and of the residual
-    int half;     // 1: half-height tiles (104 GEMM rows per workgroup instead of 208), exact-fp32 tiling B only
+    int half;     // tile height HM: 0 = 208 GEMM rows per workgroup, 1 = 104, 2 = 52, 3 = 26 (exact-fp32 tilings B / D only; conv_block.hip)
 };
 hipError_t launch_conv(const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s);
 bool conv_geom_supported(const ConvGeom& g);
