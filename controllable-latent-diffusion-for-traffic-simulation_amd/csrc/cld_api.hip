@@ -526,6 +526,8 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ca.st[4] = stage(h->down[0], CHAIN_RES_NONE, 0);
         ca.res4_w = h->res4_w; ca.res4_b = h->res4_b;
         ca.cbias = w.cb; ca.cb_stride = NCB; ca.tbias = tbr;
+        // spill slots of the chain: b[2] -- and, with the one-agent tiles (4 M-tiles of 16 rows for 52: 4,096 floats per agent instead of
+        // 3,328), the first 768 floats per agent of b[3], which follows it in the workspace; both are dead until the up path writes them
         ca.keep = b[2]; ca.y = b[6];
         ca.stamps = (h->stamp_buf && h->stamp_layer == 0) ? h->stamp_buf : nullptr;
         h->launch_counter += 5;
