@@ -169,7 +169,8 @@ hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, 
 // ---------------------------------------------------------------------------------------------------------------------
 // MapCollisionLoss (src/tbsim/utils/guidance_loss.py:717-875): agents should not leave the drivable area
 // ---------------------------------------------------------------------------------------------------------------------
-// One workgroup per plan (agent x sample), one wave per time step (13 steps each): the num_points_lw grid of sample points of
+// One workgroup of 13 waves per plan (agent x sample), one wave per time step (4 steps each: with 4 waves x 13 steps the kernel
+// was the serial chain of one wave's 13 steps -- 0.58 ms for a single 64-agent scene): the num_points_lw grid of sample points of
 // the agent's box at that step's pose (:731-753) goes to LDS with its off-road flag (drivable map at the truncated, clamped
 // raster pixel, :797-805); steps where some but not all points are off road (:807-809) then give every off-road point
 // 1 - (distance to the nearest ON-road point of the box) / (box diagonal), with the on-road point carrying the gradient and the
@@ -191,8 +192,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void map_collision_kernel(const MapCollisionArgs p) {
-    __shared__ float4 pts[4][kMaxPts];                  // per wave: x, y (agent frame), off-road flag
+constexpr int kMapWaves = 13;                           // 13 waves x 4 steps = the 52 steps of a plan
+__global__ __launch_bounds__(64 * kMapWaves) void map_collision_kernel(const MapCollisionArgs p) {
+    __shared__ float4 pts[kMapWaves][kMaxPts];          // per wave: x, y (agent frame), off-road flag
     __shared__ float part[TT];
     __shared__ float s_coef;
     const int row = blockIdx.x, b = row / p.num_samp;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void map_collision_kernel(const MapCollisionAr
     const unsigned char* dm = p.drivable_map + (size_t)b * p.H * p.W;
     float wsum = 0.f, wp = 1.f;
     for (int t = 0; t < TT; ++t) { wsum += wp; wp *= p.decay_rate; }
-    for (int t = wave; t < TT; t += 4) {
+    for (int t = wave; t < TT; t += kMapWaves) {
         const float* x = p.traj + ((size_t)row * TT + t) * 6;
         const float px = x[0], py = x[1];
         float sy, cy;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void map_collision_kernel(const MapCollisionAr
             n_off += off ? 1 : 0;
         }
         n_off = (int)wave_sum((float)n_off);
-        __syncthreads();                                // (every wave runs the same 13 iterations) the points are visible to all lanes
+        __syncthreads();                                // (every wave runs the same 4 iterations) the points are visible to all lanes
         float loss = 0.f, gx = 0.f, gy = 0.f, gyaw = 0.f;
         if (n_off != 0 && n_off != P && moving) {
             for (int j = lane; j < P; j += 64) {
@@ -241,23 +243,17 @@ __global__ __launch_bounds__(256) void map_collision_kernel(const MapCollisionAr
                 // off-road sample between two on-road neighbours): torch.amin's backward shares the gradient evenly among the minima
                 // it finds equal, which for mirror images cancels the translation part.  Candidates within 1e-5 (relative, squared
                 // distance) of the minimum are treated as that tie -- the symmetric choice, instead of whichever rounding favours.
-                float best = 3.0e38f;
+                // (one pass: candidates within 1e-5 of the running minimum accumulate; a clearly smaller one starts over)
+                float best = 3.0e38f, sx = 0.f, sy = 0.f, sw = 0.f, cnt = 0.f;
                 for (int i = 0; i < P; ++i) {
                     const float4 pi = pts[wave][i];
                     if (pi.z != 0.f) continue;
-                    const float ex = pi.x - pj.x, ey = pi.y - pj.y;
-                    best = fminf(best, ex * ex + ey * ey);
-                }
-                const float lim = best * (1.0f + 1e-5f);
-                float sx = 0.f, sy = 0.f, sw = 0.f, cnt = 0.f;
-                for (int i = 0; i < P; ++i) {
-                    const float4 pi = pts[wave][i];
-                    if (pi.z != 0.f) continue;
-                    const float ex = pi.x - pj.x, ey = pi.y - pj.y;
-                    if (ex * ex + ey * ey <= lim) {
-                        sx += ex; sy += ey; cnt += 1.f;
-                        sw += -ex * (pi.y - py) + ey * (pi.x - px);        // d p_i / d yaw = perp(p_i - pos)
-                    }
+                    const float ex = pi.x - pj.x, ey = pi.y - pj.y, d2 = ex * ex + ey * ey;
+                    if (d2 > best * (1.0f + 1e-5f)) continue;
+                    if (d2 < best * (1.0f - 1e-5f)) { sx = 0.f; sy = 0.f; sw = 0.f; cnt = 0.f; }
+                    best = fminf(best, d2);
+                    sx += ex; sy += ey; cnt += 1.f;
+                    sw += -ex * (pi.y - py) + ey * (pi.x - px);            // d p_i / d yaw = perp(p_i - pos)
                 }
                 const float d = sqrtf(best);
                 loss += 1.0f - d * inv_diag;
@@ -293,7 +289,7 @@ __global__ __launch_bounds__(256) void map_collision_kernel(const MapCollisionAr
 
 hipError_t launch_map_collision(const MapCollisionArgs& a, int rows, hipStream_t s) {
     if (a.num_points_l < 1 || a.num_points_w < 1 || a.num_points_l * a.num_points_w > kMaxPts || a.num_samp < 1 || rows < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(map_collision_kernel, dim3(rows), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(map_collision_kernel, dim3(rows), dim3(64 * kMapWaves), 0, s, a);
     return hipGetLastError();
 }
 

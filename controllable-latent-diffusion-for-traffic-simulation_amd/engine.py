@@ -339,7 +339,9 @@ class Engine:
         dm = torch.as_tensor(c["drivable_map"])
         if dm.dim() != 3 or dm.shape[0] != A:
             raise CldError(f"map_collision: drivable_map must be [{A},H,W], got {tuple(dm.shape)}")
-        dm = (dm != 0).to(self.device, torch.uint8).contiguous()
+        if not (dm.dtype == torch.uint8 and dm.device == self.device):     # (a resident uint8 map is taken as it is: non-zero = drivable)
+            dm = (dm != 0).to(self.device, torch.uint8)
+        dm = dm.contiguous()
         sizes, start, wts = self._scene_blocks(c, A, "map_collision")
         nl, nw = (int(v) for v in c.get("num_points_lw", (10, 10)))
         cc = _lib.CldMapCollision(ext.data_ptr(), rfa.data_ptr(), dm.data_ptr(), spd.data_ptr(), start.data_ptr(), wts.data_ptr(),
