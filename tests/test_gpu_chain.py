@@ -154,3 +154,21 @@ def test_chains_are_the_default_and_agree_with_the_layer_launches(B):
     e.force_kernel("unet", "chain")
     small = e.unet_forward(x[rows], cond[rows], 41)
     assert float((small.cpu() - auto.cpu()[rows]).abs().max()) <= 1e-5
+
+
+def test_chains_on_device_noise_matches_the_layer_launches():
+    """noise=None: the counter-based on-device generator is a function of (seed, step, row) only, so the tail chain -- which applies
+    the DDPM update itself on plain steps and draws its own z -- and the head kernel behind one launch per layer walk the same
+    chain; deterministic per seed, different across seeds."""
+    e = _engine(10, True, "auto")
+    B = 40
+    g = torch.Generator().manual_seed(3)
+    xT, cond = torch.randn(B, 52, 4, generator=g), torch.randn(B, 256, generator=g)
+    a, a1, _ = e.sample(xT, cond, noise=None, seed=7)
+    b, _, _ = e.sample(xT, cond, noise=None, seed=7)
+    c, _, _ = e.sample(xT, cond, noise=None, seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    e.force_kernel("unet", "layers")
+    l, l1, _ = e.sample(xT, cond, noise=None, seed=7)
+    scale = float(l.abs().max())
+    assert float((a - l).abs().max()) <= 1e-3 * scale and float((a1 - l1).abs().max()) <= 1e-3 * float(l1.abs().max())
