@@ -1275,8 +1275,20 @@ static int run_guidance(cld_handle h, const Ws& w, const cld_guidance* gd, int B
         const bool last = k == steps;
         g.opt_step = k;
         g.mean = k == 1 ? mean0 : w.gcur;
-        if (gd->collision || gd->map_collision)      // the scene / map terms are functions of the decoded plans of the current iterate
-            HIPCK(h, launch_decode(h->dec, h->dyn, g.mean, cond, gd->curr_states, nullptr, w.col_traj, B, 1, s, h->force_kernel[CLD_KERNEL_DECODE]));
+        if (gd->collision || gd->map_collision) {    // the scene / map terms are functions of the decoded plans of the current iterate
+            if (B >= 256 && guide_forward_available(B, h->force_kernel[CLD_KERNEL_GUIDE]) && h->force_kernel[CLD_KERNEL_DECODE] == FORM_AUTO) {
+                // (from the batch size at which cld_decode itself would take its 16-agent MFMA form, ~0.3 ms; below that the
+                //  one-agent-per-workgroup decoder is the shorter chain: 64 agents 579 vs 616 us per collision-guided step)
+                // the guidance kernel's own forward sweep as the decoder (8 agents per workgroup: the whole chip at 2,048 agents), then
+                // the O(T) roll-out; the actions wait in the gradient buffer the loss kernels fill afterwards
+                GuideArgs gf{};
+                gf.mean = g.mean; gf.cond = cond; gf.curr_states = gd->curr_states; gf.scratch = w.guide; gf.B = B; gf.act_out = w.col_grad;
+                HIPCK(h, launch_guide_forward(h->dec, h->dyn, gf, s));
+                HIPCK(h, launch_action_to_state(h->dyn, w.col_grad, gd->curr_states, w.col_traj, B, 1, 1, s));
+            } else {
+                HIPCK(h, launch_decode(h->dec, h->dyn, g.mean, cond, gd->curr_states, nullptr, w.col_traj, B, 1, s, h->force_kernel[CLD_KERNEL_DECODE]));
+            }
+        }
         if (gd->collision) {
             const cld_collision* c = gd->collision;
             CollisionArgs ca{};

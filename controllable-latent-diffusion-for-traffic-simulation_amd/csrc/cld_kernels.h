@@ -260,6 +260,7 @@ struct GuideArgs {
     float* x_out;               // guided mean + sigma z, [>=B,52,4] or null
     float* x_out2;              // second copy (the unconditional half in CFG mode) or null
     float* grad_out;            // dL/dmean [B,52,4] or null (diagnostic / tests)
+    float* act_out;             // launch_guide_forward only: scaled decoder actions [B,52,2]; the kernel stops behind its forward sweep
     float* scratch;             // guide_scratch_floats(B) floats
     float lr, perturb_th, sigma;
     int optimizer;              // 0 = Adam, 1 = SGD
@@ -276,6 +277,8 @@ struct GuideArgs {
 size_t guide_scratch_floats(int B);
 void read_guide_stamps(unsigned long long* out);     // -DCLD_STAMPS builds: 8 shader-clock stamps per workgroup (256 workgroups); else a no-op
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form = FORM_AUTO);
+bool guide_forward_available(int B, int form = FORM_AUTO);
+hipError_t launch_guide_forward(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s);
 
 // per-agent values of the built-in guidance losses on a decoded trajectory (include/cld.h cld_guidance_losses); uses the loss
 // fields of GuideArgs (target_speed, loss_scale, speed/acc limits, waypoint) and B

@@ -1361,6 +1361,14 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
             act[o][t][ag] = (o ? bh2b : bh2a) + actp[t][o][0][ag] + actp[t][o][1][ag] + actp[t][o][2][ag] + actp[t][o][3][ag];
         }
         __syncthreads();
+        if (a.act_out) {       // forward only: the decoder's scaled actions of this group (the caller rolls them out); see launch_guide_forward
+            for (int i = tid; i < 2 * GT * AG; i += 512) {
+                const int ag = i / (2 * GT), t = (i >> 1) % GT, o = i & 1;
+                if (b0 + ag < a.B) a.act_out[((size_t)(b0 + ag) * GT + t) * 2 + o] = act[o][t][ag];
+            }
+            __syncthreads();
+            continue;
+        }
         chain_grad_group<AG, 512>(d, a, agent, &act[0][0][0], &act[1][0][0], AG, &dact[0][0][0], &chs[0][0]);
         GSTAMP(4);
         // ---------------- backward through time ----------------
@@ -1514,6 +1522,16 @@ size_t guide_scratch_floats(int B) {
     const size_t valu = (size_t)guide_grid(B) * GNA * (G_GATES + G_CELLS);
     const size_t mfma = (size_t)guide_mfma_grid(B) * gm8::ACTS, quad = (size_t)guide_quad_grid(B) * gq::ACTS;
     return valu > mfma ? (valu > quad ? valu : quad) : (mfma > quad ? mfma : quad);
+}
+
+// The forward half of the 8-agent kernel as a decoder: 256 workgroups at 2,048 agents where decode_mfma_kernel (16 agents per
+// workgroup) fills half the chip.  Used for the plans the scene-coupled guidance losses are evaluated on (cld_api.hip
+// run_guidance), where a decode precedes every guidance-kernel launch.  False: this batch size does not take the 8-agent form.
+bool guide_forward_available(int B, int form) { return guide_form(B, form) == FORM_MFMA_QUAD; }
+hipError_t launch_guide_forward(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s) {
+    if (!a.act_out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(512), 0, s, w, d, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
