@@ -52,7 +52,7 @@ struct cld_handle_s {
     cld_config cfg{};
     int stride = 1;                                  // DmModel.stride (dm_model.py:25,119): the loop visits i = ..., 2 stride, stride, 0
     int precision = CLD_PRECISION_F32;               // cfg.precision
-    int force_kernel[4] = {0, 0, 0, 0};              // cld_debug_force_kernel: formulation of the guide / decode / encode kernels and of the U-Net's layer chains (0 = by batch size)
+    int force_kernel[5] = {0, 0, 0, 0, 0};           // cld_debug_force_kernel: formulation of the guide / decode / encode kernels, of the U-Net's layer chains and of the ContextEncoder's 3x3 convolutions (0 = the library's choice)
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
     std::map<std::string, size_t> expect;            // name -> numel
@@ -73,7 +73,7 @@ struct cld_handle_s {
     EncoderWeights enc{};
     bool has_encoder = false;
     // ContextEncoder (optional): stem, 19 NHWC convolutions, head
-    struct Conv2dLayer { float *wfrag = nullptr, *scale = nullptr, *shift = nullptr; int kh = 3, stride = 1, hin = 56, cin = 64, cout = 64; };
+    struct Conv2dLayer { float *wfrag = nullptr, *ufrag = nullptr, *scale = nullptr, *shift = nullptr; int kh = 3, stride = 1, hin = 56, cin = 64, cout = 64; };   // ufrag: the Winograd-domain filters of a 3x3 / stride-1 layer (wino_kernels.hip)
     bool has_context = false;
     float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
     Conv2dLayer rn_conv[4][2][2], rn_ds[4];
@@ -692,7 +692,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 3 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 4 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 4 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 4 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }
@@ -1050,6 +1050,24 @@ int cld_finalize(cld_handle h, void* stream) {
             std::vector<float> packed = pack_conv_weights(wget, cout, cin, kh * kh);
             UP(l.wfrag, packed);
             l.kh = kh; l.stride = stride; l.hin = hin; l.cin = cin; l.cout = cout;
+            if (kh == 3 && stride == 1 && cin == cout) {
+                // Winograd F(2x2, 3x3): U[xi = 4 i + j][ci][co] = (G g G^T)[i][j], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], formed in double
+                static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+                std::vector<float> U((size_t)16 * cin * cout);
+                for (int co = 0; co < cout; ++co)
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const float* g = &W[((size_t)co * cin + ci) * 9];
+                        double t[4][3];
+                        for (int i = 0; i < 4; ++i)
+                            for (int b = 0; b < 3; ++b) t[i][b] = Gm[i][0] * g[b] + Gm[i][1] * g[3 + b] + Gm[i][2] * g[6 + b];
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j)
+                                U[((size_t)(4 * i + j) * cin + ci) * cout + co] = (float)(t[i][0] * Gm[j][0] + t[i][1] * Gm[j][1] + t[i][2] * Gm[j][2]);
+                    }
+                auto uget = [&](int co, int ci, int xi) -> float { return U[((size_t)xi * cin + ci) * cout + co]; };
+                std::vector<float> upacked = pack_conv_weights(uget, cout, cin, 16);
+                UP(l.ufrag, upacked);
+            }
             return fold_bn(bnname, &l.scale, &l.shift);
         };
         int cin = 64, hin = 56;
@@ -1576,7 +1594,9 @@ int cld_context_encode(cld_handle h, const float* image, const float* curr_state
     float* y1 = static_cast<float*>(workspace);
     float* buf[3];
     for (int i = 0; i < 3; ++i) buf[i] = y1 + (size_t)cb * kStemFloats + (size_t)i * cb * kActFloats;
+    const bool wino = h->force_kernel[CLD_KERNEL_CONTEXT] != CLD_FORM_DIRECT;
     auto run = [&](const cld_handle_s::Conv2dLayer& l, const float* x, const float* res, float* y, int relu, int n) {
+        if (wino && l.ufrag) return launch_wino_conv(l.hin, l.cout, WinoArgs{x, l.ufrag, l.scale, l.shift, res, y, n, relu}, s);
         return launch_conv2d(l.kh, l.stride, l.hin, x, l.wfrag, l.scale, l.shift, res, y, n, l.cin, l.cout, relu, s);
     };
     for (int b0 = 0; b0 < B; b0 += cb) {

@@ -227,6 +227,18 @@ hipError_t launch_maxpool(const float* x, float* y, int B, hipStream_t s);
 // hin = input height = width in {56, 28, 14, 7}; wfrag in pack_conv_weights layout (tap = kh * KW + kw)
 hipError_t launch_conv2d(int kh, int stride, int hin, const float* x, const float* wfrag, const float* scale,
                          const float* shift, const float* res, float* y, int B, int cin, int cout, int relu, hipStream_t s);
+// 3x3 / stride 1 / pad 1 convolution with C_in = C_out by Winograd F(2x2, 3x3) (wino_kernels.hip) + folded BatchNorm [+ residual]
+// [+ ReLU]; ufrag: U = G g G^T in pack_conv_weights layout with the 16 transform-domain positions as "taps"; B <= 256
+struct WinoArgs {
+    const float* x;        // [B, H, H, C] NHWC
+    const float* ufrag;
+    const float* scale;    // [C] folded BatchNorm
+    const float* shift;
+    const float* res;      // [B, H, H, C] or null
+    float* y;              // [B, H, H, C]
+    int B, relu;
+};
+hipError_t launch_wino_conv(int hin, int channels, const WinoArgs& a, hipStream_t s);
 struct ContextHeadArgs {
     const float* feat;          // [B,7,7,512] NHWC, layer4 output
     const float* curr_states;   // [B,4]

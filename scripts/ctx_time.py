@@ -7,6 +7,7 @@ from cld_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = Engine(n_timesteps=10)
 eng.load_state_dict(synth.make_unet_weights(0)); eng.load_state_dict(synth.make_context_weights(0)); eng.finalize()
+if len(sys.argv) > 2: eng.force_kernel("context", sys.argv[2])      # direct | winograd: the 3x3 / stride-1 convolutions
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 img = torch.empty(B, 34, 224, 224, device="cuda").uniform_(-1, 1, generator=g)
 cs = torch.rand(B, 4, device="cuda", generator=g)
@@ -21,4 +22,4 @@ for tag in ("dense", "structured"):
     t = time.perf_counter()
     for _ in range(3): eng.context_encode(img, cs)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 3
-    print(f"{tag}: B={B} {dt*1e3:.2f} ms  {B/dt:.0f} agents/s  {B*6.062e9/dt/1e12:.1f} dense-equivalent TFLOP/s")
+    print(f"{sys.argv[2] if len(sys.argv) > 2 else 'auto'} {tag}: B={B} {dt*1e3:.2f} ms  {B/dt:.0f} agents/s  {B*6.062e9/dt/1e12:.1f} dense-equivalent TFLOP/s")

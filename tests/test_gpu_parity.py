@@ -316,6 +316,35 @@ def test_context_encoder_vs_oracle(eng_ctx, B, dense):
     assert (cond.cpu() - ref).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("B", [1, 5, 67])
+def test_context_winograd_and_direct_convolutions_agree(eng_ctx, B):
+    """The 3x3 / stride-1 convolutions of the ResNet-18 run as Winograd F(2x2, 3x3) (wino_kernels.hip) by default and as the
+    implicit GEMM of the other convolutions on request: two kernels, one function.  Ragged tile lists (B = 1: 784 / 196 / 49 / 16
+    tiles of 2x2 outputs in workgroups of 32; the 7x7 map's tiles hang over its edge), against each other and against the oracle."""
+    from oracle import cld_oracle as O
+    img = torch.from_numpy(synth.make_raster(B, 13, dense=True))
+    cs = torch.from_numpy(synth.make_inputs(B, 13)["curr_states"])
+    try:
+        eng_ctx.force_kernel("context", "direct")
+        cd, md = eng_ctx.context_encode(img.cuda(), cs.cuda(), want_map_feat=True)
+        cd, md = cd.clone(), md.clone()
+        eng_ctx.force_kernel("context", "winograd")
+        cw, mw = eng_ctx.context_encode(img.cuda(), cs.cuda(), want_map_feat=True)
+    finally:
+        eng_ctx.force_kernel("context", "auto")
+    ca, ma = eng_ctx.context_encode(img.cuda(), cs.cuda(), want_map_feat=True)
+    assert torch.equal(ca, cw) and torch.equal(ma, mw)            # the default IS the Winograd form
+    assert not torch.equal(md, mw)                                # two different kernels ran
+    scale = float(md.abs().max())
+    assert float((md - mw).abs().max()) <= 2e-5 * scale
+    assert float((cd - cw).abs().max()) <= 2e-5
+    if B <= 5:
+        taps = {}
+        ref = O.context_encode(O.to_torch(synth.make_context_weights(0)), img, cs, taps)
+        assert (mw.cpu() - taps["map_feat"]).abs().max().item() <= 1e-4 * scale
+        assert (cw.cpu() - ref).abs().max().item() <= 1e-4
+
+
 def test_context_encoder_agents_are_independent(eng_ctx):
     """Size-independent property: every agent's cond_feat depends on its own raster / state only, so a 261-agent batch
     (two passes of <= 256 agents, ragged tiles) built by repeating 3 agents must reproduce their rows bit for bit."""
