@@ -1573,6 +1573,26 @@ namespace {
 constexpr int kCtxChunk = 256;                               // agents per pass: bounds the activation scratch
 constexpr size_t kStemFloats = (size_t)112 * 112 * 64;       // per agent
 constexpr size_t kActFloats = (size_t)56 * 56 * 64;          // largest post-pool activation per agent
+
+// Agents per pass of the ContextEncoder.  The Winograd kernels (wino_kernels.hip) run n * (784 | 196 | 49 | 16) / 32 * (C / 64) equal
+// workgroups per launch, two to a CU: at n = 256 that is 12.25 / 6.125 / 3.06 / 2 generations of 512 -- the last generation of the 14x14
+// launches is 6 % full and costs a whole one.  At n = 250 the counts are 11.96 / 5.98 / 2.99 / 1.95.  The pass size is the one that
+// minimises the modelled generation count of the whole batch (a generation of the 56x56 / 28x28 / 14x14 / 7x7 launches lasts 1 / 2 / 4 / 8
+// units: 4 / 8 / 16 / 32 K chunks), with a fixed cost per pass for its 27 launches.
+int context_pass_size(int B) {
+    if (B <= kCtxChunk) return B;
+    auto cost = [](int n) {
+        auto gens = [&](int tiles_per_agent, int ncb) { return (long)((n * tiles_per_agent + 31) / 32 * ncb + 511) / 512; };
+        return 4 * gens(784, 1) * 1 + 3 * gens(196, 2) * 2 + 3 * gens(49, 4) * 4 + 3 * gens(16, 8) * 8 + 6;
+    };
+    int best = kCtxChunk;
+    long best_cost = -1;
+    for (int p = kCtxChunk; p >= 128; --p) {
+        long c = (long)(B / p) * cost(p) + (B % p ? cost(B % p) : 0);
+        if (best_cost < 0 || c < best_cost) { best_cost = c; best = p; }
+    }
+    return best;
+}
 }
 size_t cld_context_workspace_bytes(cld_handle h, int32_t B) {
     if (!h || B < 1) return 0;
@@ -1599,8 +1619,9 @@ int cld_context_encode(cld_handle h, const float* image, const float* curr_state
         if (wino && l.ufrag) return launch_wino_conv(l.hin, l.cout, WinoArgs{x, l.ufrag, l.scale, l.shift, res, y, n, relu}, s);
         return launch_conv2d(l.kh, l.stride, l.hin, x, l.wfrag, l.scale, l.shift, res, y, n, l.cin, l.cout, relu, s);
     };
-    for (int b0 = 0; b0 < B; b0 += cb) {
-        const int n = (B - b0) < cb ? (B - b0) : cb;
+    const int pass = wino ? context_pass_size(B) : cb;
+    for (int b0 = 0; b0 < B; b0 += pass) {
+        const int n = (B - b0) < pass ? (B - b0) : pass;
         HIPCK(h, launch_stem_conv(image + (size_t)b0 * 34 * 224 * 224, h->stem_w, h->stem_scale, h->stem_shift, y1, n, s));
         HIPCK(h, launch_maxpool(y1, buf[0], n, s));
         int xi = 0;                                            // buffer holding the current block input
