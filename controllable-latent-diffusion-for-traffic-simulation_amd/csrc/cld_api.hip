@@ -35,6 +35,7 @@ struct ConvLayer {
     ConvGeom g{};        // kc / nwn / ks are filled per launch by pick_tiling()
     bool has_a = false, has_b = false;   // which tilings have a kernel instance
     float *wfrag = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;
+    float* ufrag = nullptr;   // Winograd-domain filters G g of a layer wino1d_kernels.hip can run (exact-fp32 handles)
     int c_out = 0, c1_real = 0, c1_pad = 0, c2 = 0, ly = 0, off0 = 0, orow0 = 0;
     int cb_off = -1;    // offset into the 1792-wide cond/time bias rows, -1 = none
 };
@@ -52,7 +53,7 @@ struct cld_handle_s {
     cld_config cfg{};
     int stride = 1;                                  // DmModel.stride (dm_model.py:25,119): the loop visits i = ..., 2 stride, stride, 0
     int precision = CLD_PRECISION_F32;               // cfg.precision
-    int force_kernel[5] = {0, 0, 0, 0, 0};           // cld_debug_force_kernel: formulation of the guide / decode / encode kernels, of the U-Net's layer chains and of the ContextEncoder's 3x3 convolutions (0 = the library's choice)
+    int force_kernel[6] = {0, 0, 0, 0, 0, 0};           // cld_debug_force_kernel: formulation of the guide / decode / encode kernels, of the U-Net's layer chains and of the ContextEncoder's 3x3 convolutions (0 = the library's choice)
     std::string err;
     std::map<std::string, std::vector<float>> w;     // host copies keyed by reference state_dict name
     std::map<std::string, size_t> expect;            // name -> numel
@@ -412,10 +413,23 @@ ConvArgs make_args(cld_handle h, const ConvLayer& l, const float* x1, const floa
 // One conv launch; launches of the dominant kernel shape (k5 + GroupNorm + Mish block producing 256 channels at L = 13) are
 // bracketed by HIP events in every kProfStride-th U-Net evaluation while profiling is on: an event pair costs ~2 us of stream
 // time, and bracketing all 800 such launches of a 100-step sample call slowed the timed region itself by 5 %.
+constexpr int kWino1dMinRows = 1024;      // launch sets of at least this many rows take the Winograd form of the 256 -> 256 layers
+bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
+    if (!l.ufrag || h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_DIRECT) return false;
+    return h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_WINOGRAD || b_pad >= kWino1dMinRows;
+}
+hipError_t launch_one(cld_handle h, const ConvLayer& l, const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
+    if (use_wino1d(h, l, b_pad)) {
+        ConvArgs w = a;
+        w.wfrag = l.ufrag;
+        return launch_wino1d(w, l.g.l_in, l.c1_real, b_pad, s);
+    }
+    return launch_conv(g, a, b_pad, s);
+}
 hipError_t launch_maybe_timed(cld_handle h, const ConvLayer& l, const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
     const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && g.epi == EPI_GN_MISH && l.c_out == 256 &&
                        (h->eval_counter % kProfStride) == 0;
-    if (!timed) return launch_conv(g, a, b_pad, s);
+    if (!timed) return launch_one(h, l, g, a, b_pad, s);
     if (h->prof_used + 2 > h->prof_ev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t ev;
@@ -426,7 +440,7 @@ hipError_t launch_maybe_timed(cld_handle h, const ConvLayer& l, const ConvGeom& 
     }
     hipError_t e = hipEventRecord(h->prof_ev[h->prof_used], s);
     if (e != hipSuccess) return e;
-    e = launch_conv(g, a, b_pad, s);
+    e = launch_one(h, l, g, a, b_pad, s);
     if (e != hipSuccess) return e;
     e = hipEventRecord(h->prof_ev[h->prof_used + 1], s);
     h->prof_used += 2;
@@ -692,7 +706,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 4 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 4 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 4 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }
@@ -795,6 +809,24 @@ int cld_finalize(cld_handle h, void* stream) {
                                     : ain       ? pack_conv_weights_split(wget, c_out, c1_pad + c2, ntaps)
                                                 : pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
         UP(l.wfrag, packed);
+        if (!split && !transposed && stride == 1 && ntaps == 5 && epi == EPI_GN_MISH && c2 == 0 && wino1d_supported(L_in, c1_real, c_out)) {
+            // F(4, 5) at the points {0, +-1, +-2, +-1/2, inf}: U[xi][ci][co] = sum_k G[xi][k] w[co][ci][k], in double
+            static const double Gm[8][5] = {{-1, 0, 0, 0, 0},
+                                            {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                            {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                            {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                            {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                            {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                            {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                            {0, 0, 0, 0, 1}};
+            auto uget = [&](int co, int ci, int xi) -> float {
+                double u = 0.0;
+                for (int k = 0; k < 5; ++k) u += Gm[xi][k] * (double)W[((size_t)co * cin_real + ci) * kw + k];
+                return (float)u;
+            };
+            std::vector<float> upacked = pack_conv_weights(uget, c_out, c1_real, 8);
+            UP(l.ufrag, upacked);
+        }
         UP(l.bias, *getw(h, wname + ".bias"));
         if (epi == EPI_GN_MISH) {
             UP(l.gamma, *getw(h, gn_name + ".weight"));

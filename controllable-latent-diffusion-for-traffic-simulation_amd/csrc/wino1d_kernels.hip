@@ -1,0 +1,281 @@
+// wino1d_kernels.hip -- Conv1d(k = 5, pad 2) + GroupNorm(8) + Mish [+ cond / time vector] [+ residual] of TemporalMapUnet's
+// 256-channel level (reference: Conv1dBlock, src/tbsim/models/diffuser_helpers.py:34-67, inside ResidualTemporalMapBlockConcat,
+// src/tbsim/models/temporal.py:18-60; the seven 256 -> 256 launches at L = 13 of a U-Net evaluation, 50 % of its FLOPs) by
+// Winograd / Cook-Toom minimal filtering F(4, 5).
+//
+// conv_block.hip runs these launches at the clock-adjusted ceiling of the fp32 MFMA pipe: what is left to take out is
+// the arithmetic.  Four outputs of a 5-tap correlation need 8 multiplies instead of 20 when the filter and the 8-row input tile
+// d = x[4t - 2 .. 4t + 5] are taken to the points {0, +-1, +-2, +-1/2, inf}:
+//     y[4t .. 4t + 3] = A^T [ (G g) (.) (B^T d) ]
+//     B^T = [ -1  0  21/4   0   -21/4   0    1  0        A^T = [ 1 1  1 1  1  1    1   0
+//              0  1   1   -17/4 -17/4   1    1  0                0 1 -1 2 -2 1/2 -1/2  0
+//              0 -1   1    17/4 -17/4  -1    1  0                0 1  1 4  4 1/4  1/4  0
+//              0 1/2 1/4   -5/2  -5/4   2    1  0                0 1 -1 8 -8 1/8 -1/8  1 ]
+//              0 -1/2 1/4   5/2  -5/4  -2    1  0
+//              0  2   4    -5/2  -5    1/2   1  0
+//              0 -2   4     5/2  -5   -1/2   1  0
+//              0 -1   0    21/4   0   -21/4  0  1 ]
+// (every entry exact in fp32; G g is formed in double at cld_finalize).  The sum over input channels moves inside the element-wise
+// product: 8 GEMMs  M_xi[row][n] = sum_c V_xi[row][c] U_xi[c][n]  over rows = (agent, tile).  L = 13 is four tiles per agent (16
+// outputs, three discarded), so a launch issues 8 x 4 MFMA k-steps per agent and channel pair where the direct form issues
+// 5 x 13: 2.03x fewer.  Rounding: 9e-7 of max|y| against fp64 on unit-variance data, the direct form 6e-7 (one-dimensional transforms
+// do not square the constants the way F(4x4, 3x3) does).
+//
+// Kernel (the structure of wino_kernels.hip): a workgroup owns 16 agents = 64 rows = four M-tiles x 64 output channels x the 8 xi;
+// wave w holds the 32 accumulators of channels 16 w .. 16 w + 15; the filters are the MFMA's A operand and the rows its B operand, so
+// a lane ends up with four consecutive channels of one (agent, tile).  Per 16-channel chunk a thread fetches the 8 input rows of one
+// (agent, tile) x four channels (eight 16-byte loads, issued two blocks' worth of latency ahead), applies B^T in the shadow of the
+// MFMAs and writes V[xi][row][16 channels] into one of two LDS images (64-byte rows, 16-byte slots permuted so the four 16-lane groups
+// of a ds_read_b128 touch every bank once).  U comes from L2 in MFMA fragment order (pack_conv_weights with xi as the tap), four items
+// ahead.  Epilogue in registers: A^T, conv bias, two-pass GroupNorm statistics (a group = 32 channels = two waves: DPP + permlane
+// sums inside the wave, 2 x 64 floats of LDS between the two), affine, Mish, vectors, residual, 16-byte stores.
+// Workgroup id -> (agent group, channel block) keeps the four channel blocks of an agent group on one XCD (they stage the same rows).
+#include "cld_kernels.h"
+
+#ifndef CLD_STORE_AUX
+#define CLD_STORE_AUX 16
+#endif
+
+namespace cld {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ int hsw1(int k) { return ((k & 1) * 3) ^ (k >> 1); }      // wino_kernels.hip hsw
+
+#define W1_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+// sum over the 4 lanes of a quad (the four tiles of an agent) and the 4 lane groups (channel quads), left in every lane involved
+__device__ __forceinline__ float agent_sum(float s) {
+    s += W1_DPP(s, 0xB1);       // quad_perm:[1,0,3,2]
+    s += W1_DPP(s, 0x4E);       // quad_perm:[2,3,0,1]
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+    const unsigned a16 = r16[0], b16 = r16[1];      // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0)
+    s = __builtin_bit_cast(float, a16) + __builtin_bit_cast(float, b16);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
+    const unsigned a32 = r32[0], b32 = r32[1];
+    return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);
+}
+__device__ __forceinline__ float mish1(float x) {      // conv_block.hip mish_f
+    const float e = __expf(fminf(x, 30.0f));
+    const float n = e * (e + 2.0f);
+    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+}
+
+template <int L_, int C_>
+struct W1Geo {
+    static constexpr int L = L_, C = C_;
+    static constexpr int TPA = (L + 3) / 4;            // tiles per agent
+    static constexpr int AG = 64 / TPA;                // agents per workgroup: 64 rows = four M-tiles
+    static constexpr int KC = 16, NCH = C / KC, NCB = C / 64, NTN = C / 16;
+    static constexpr int VBUF = 8 * 64 * KC;           // floats per V image
+    static constexpr size_t LDS_BYTES = (2 * VBUF + 2 * 64) * sizeof(float);
+    static_assert(TPA == 4, "four tiles per agent: a quad of lanes is an agent");
+    static_assert(NCH % 2 == 0, "chunk pairs are unrolled");
+};
+
+}  // namespace
+
+template <int L, int C>
+__global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map) {
+    typedef W1Geo<L, C> G;
+    extern __shared__ __attribute__((aligned(16))) float lds1[];
+    float* xch = lds1 + 2 * G::VBUF;                   // [2][4 waves][16 agents]: the GroupNorm sums of the two waves of a group meet here
+    const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int cb, grp;
+    if (xcd_map) {                                     // ids x, x + 8, x + 16, x + 24: one agent group, one XCD, back to back
+        cb = (blockIdx.x >> 3) & 3;
+        grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
+    } else {
+        cb = blockIdx.x % G::NCB;
+        grp = blockIdx.x / G::NCB;
+    }
+    const int b0 = grp * G::AG;
+
+    // ---- staging role: row rs = (agent rs / 4, tile rs % 4), channels 4 c4 .. 4 c4 + 3 of the chunk ----
+    const int rs = tid >> 2, c4 = tid & 3;
+    const int total_bytes = b_pad * L * C * 4;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, total_bytes, 0x00020000);
+    int voff[8];
+    {
+        const int a = rs >> 2, t = rs & 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int pos = 4 * t - 2 + i;
+            voff[i] = (pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * C + 4 * c4) * 4 : total_bytes;      // the zero padding: out of range reads 0
+        }
+    }
+    v4f d[8];
+    auto patch_load = [&](const int i, const int c) {
+        d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff[i], c * (G::KC * 4), 0));
+    };
+    const int wofs = rs * 16 + ((((rs >> 2) & 3) ^ hsw1(c4)) << 2);
+    // B^T d in four pieces (xi pairs share their even / odd halves), each stored as it is formed
+    auto transform_piece = [&](const int k, const int buf) {
+        float* vb = lds1 + buf * G::VBUF + wofs;
+        auto st = [&](const int xi, const v4f v) { *reinterpret_cast<v4f*>(vb + xi * (64 * 16)) = v; };
+        if (k == 0) {
+            const v4f e = (d[2] + d[6]) - 4.25f * d[4], o = (d[1] + d[5]) - 4.25f * d[3];
+            st(1, e + o); st(2, e - o);
+        } else if (k == 1) {
+            const v4f e = (0.25f * d[2] - 1.25f * d[4]) + d[6], o = (0.5f * d[1] - 2.5f * d[3]) + 2.0f * d[5];
+            st(3, e + o); st(4, e - o);
+        } else if (k == 2) {
+            const v4f e = (4.0f * d[2] - 5.0f * d[4]) + d[6], o = (2.0f * d[1] - 2.5f * d[3]) + 0.5f * d[5];
+            st(5, e + o); st(6, e - o);
+        } else {
+            st(0, (d[6] - d[0]) + 5.25f * (d[2] - d[4]));
+            st(7, (d[7] - d[1]) + 5.25f * (d[3] - d[5]));
+        }
+    };
+
+    // ---- MFMA role: lane (i16, kk) of wave w: rows 16 m + i16, channels 4 kk .. 4 kk + 3 of the chunk, output channels 16 w .. ----
+    const char* ldsb = reinterpret_cast<const char*>(lds1);
+    const int abase = (i16 * 16 + ((((i16 >> 2) & 3) ^ hsw1(kk)) << 2)) * 4;
+    const int nitems = G::NCH * 8;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wfrag), 0, nitems * G::NTN * 1024, 0x00020000);
+    const int wvoff = lane * 16;
+    const int wsoff = (cb * 4 + wave) * 1024;
+    auto wload = [&](int item) {          // item = chunk * 8 + xi; past the end: out of range, reads 0, never used
+        return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff, item * (G::NTN * 1024) + wsoff, 0));
+    };
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[xi][m] = v4f{0.f, 0.f, 0.f, 0.f};
+    v4f bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = wload(i);
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) patch_load(i, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) transform_piece(k, 0);
+    __syncthreads();
+
+    // one chunk: 8 xi x 4 M-tiles x 4 MFMAs.  Fragments run two (xi, M-tile) items ahead of their MFMAs (a rolling window of three);
+    // the next chunk's rows are requested during xi = 0, 1 and transformed during xi = 4 .. 7
+    auto mfma_block = [&](const int buf, const int c, const bool stage) {
+        const int bo = buf * (G::VBUF * 4);
+        auto frag = [&](const int it) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + (it >> 2) * 4096 + (it & 3) * 1024); };
+        v4f ar[3];
+        ar[0] = frag(0);
+        ar[1] = frag(1);
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) {
+            const v4f bcur = bq[xi & 3];
+            bq[xi & 3] = wload(c * 8 + xi + 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int it = 4 * xi + m;
+                if (it + 2 < 32) ar[(it + 2) % 3] = frag(it + 2);
+                if (stage && xi < 2) { patch_load(4 * xi + m, c + 1); }
+                if (stage && xi >= 4 && m == 1) transform_piece(xi - 4, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[xi][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[e], ar[it % 3][e], acc[xi][m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+#pragma clang loop unroll(disable)
+    for (int c = 0; c < G::NCH; c += 2) {
+        mfma_block(0, c, true);
+        __syncthreads();
+        const bool more = c + 2 < G::NCH;
+        mfma_block(1, c + 1, more);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  Lane: channels n4 .. n4 + 3; M-tile m: agent b0 + 4 m + i16 / 4, tile t = i16 % 4, outputs at 4 t + o ----
+    const int n4 = cb * 64 + 16 * wave + 4 * kk;
+    const int t = i16 & 3;
+    const v4f bias = *reinterpret_cast<const v4f*>(p.bias + n4);
+    v4f Y[4][4];                                         // [m][o]
+    float s1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const v4f p12 = acc[1][m] + acc[2][m], m12 = acc[1][m] - acc[2][m];
+        const v4f p34 = acc[3][m] + acc[4][m], m34 = acc[3][m] - acc[4][m];
+        const v4f p56 = acc[5][m] + acc[6][m], m56 = acc[5][m] - acc[6][m];
+        Y[m][0] = ((acc[0][m] + p12) + (p34 + p56)) + bias;
+        Y[m][1] = ((m12 + 2.0f * m34) + 0.5f * m56) + bias;
+        Y[m][2] = ((p12 + 4.0f * p34) + 0.25f * p56) + bias;
+        Y[m][3] = (((m12 + 8.0f * m34) + 0.125f * m56) + acc[7][m]) + bias;
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (4 * t + o < L) s += (Y[m][o][0] + Y[m][o][1]) + (Y[m][o][2] + Y[m][o][3]);
+        s1[m] = agent_sum(s);
+    }
+    // GroupNorm(32 channels x L rows per agent, eps 1e-5, biased variance, two passes; diffuser_helpers.py:61): the group's other
+    // half lives in wave w ^ 1
+    const float inv = 1.0f / (float)(32 * L);
+    if (kk == 0 && t == 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xch[wave * 16 + 4 * m + (i16 >> 2)] = s1[m];
+    }
+    __syncthreads();
+    float mean[4], s2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        mean[m] = (s1[m] + xch[(wave ^ 1) * 16 + 4 * m + (i16 >> 2)]) * inv;
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (4 * t + o < L) {
+                const v4f dv = Y[m][o] - mean[m];
+                s += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+            }
+        s2[m] = agent_sum(s);
+    }
+    if (kk == 0 && t == 0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xch[64 + wave * 16 + 4 * m + (i16 >> 2)] = s2[m];
+    }
+    __syncthreads();
+    const v4f gam = *reinterpret_cast<const v4f*>(p.gamma + n4), bet = *reinterpret_cast<const v4f*>(p.beta + n4);
+    const v4f tb = p.tbias ? *reinterpret_cast<const v4f*>(p.tbias + n4) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int b = b0 + 4 * m + (i16 >> 2);
+        const float var = (s2[m] + xch[64 + (wave ^ 1) * 16 + 4 * m + (i16 >> 2)]) * inv;
+        const v4f sc = (1.0f / sqrtf(var + 1e-5f)) * gam;
+        v4f add = tb;
+        if (p.cbias) add += *reinterpret_cast<const v4f*>(p.cbias + (size_t)b * p.cb_stride + n4);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int pos = 4 * t + o;
+            if (pos >= L) continue;
+            const v4f x = (Y[m][o] - mean[m]) * sc + bet;
+            v4f v = v4f{mish1(x[0]), mish1(x[1]), mish1(x[2]), mish1(x[3])} + add;
+            const size_t oidx = ((size_t)b * L + pos) * C + n4;
+            if (p.res) v += *reinterpret_cast<const v4f*>(p.res + oidx);
+            *reinterpret_cast<v4f*>(p.y + oidx) = v;
+        }
+    }
+}
+
+bool wino1d_supported(int l_in, int c_in, int c_out) { return l_in == 13 && c_in == 256 && c_out == 256; }
+
+hipError_t launch_wino1d(const ConvArgs& a, int l_in, int c_in, int b_pad, hipStream_t s) {
+    if (!wino1d_supported(l_in, c_in, a.c_out) || b_pad < 16 || b_pad % 16 || a.x2 || a.c2 || a.res4_x) return hipErrorInvalidValue;
+    if ((long)b_pad * 13 * 256 * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
+    typedef W1Geo<13, 256> G;
+    auto kern = wino1d_conv_kernel<13, 256>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int groups = b_pad / G::AG;
+    hipLaunchKernelGGL(kern, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace cld

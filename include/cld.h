@@ -444,6 +444,8 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
                                * per layer (conv_block.hip), CLD_FORM_CHAIN the LDS-resident layer chains (conv_chain.hip) */
 #define CLD_KERNEL_CONTEXT 4  /* the 3x3 / stride-1 convolutions of the ContextEncoder: CLD_FORM_AUTO / CLD_FORM_WINOGRAD Winograd F(2x2, 3x3)
                                * (wino_kernels.hip), CLD_FORM_DIRECT the implicit-GEMM kernel the other convolutions use */
+#define CLD_KERNEL_CONV5 5    /* the 256 -> 256 Conv1d(k5) + GroupNorm + Mish launches of a U-Net evaluation (exact-fp32 handles): CLD_FORM_AUTO
+                               * by batch size, CLD_FORM_DIRECT conv_block.hip, CLD_FORM_WINOGRAD Winograd F(4, 5) (wino1d_kernels.hip) */
 #define CLD_FORM_AUTO 0       /* by batch size (default) */
 #define CLD_FORM_VALU 1       /* one or two agents per workgroup, gate rows in registers */
 #define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 16x16x4 MFMA tiles */
@@ -452,8 +454,8 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only: chains, tile (4 agents | 1 agent per workgroup) by batch size */
 #define CLD_FORM_CHAIN_TILE1 3   /* CLD_KERNEL_UNET only: chains with one-agent tiles  */
 #define CLD_FORM_CHAIN_TILE4 4   /* CLD_KERNEL_UNET only: chains with four-agent tiles */
-#define CLD_FORM_DIRECT 1     /* CLD_KERNEL_CONTEXT only */
-#define CLD_FORM_WINOGRAD 2   /* CLD_KERNEL_CONTEXT only */
+#define CLD_FORM_DIRECT 1     /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
+#define CLD_FORM_WINOGRAD 2   /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);
 
 /* CLD_PRECISION_* the handle runs with. */
