@@ -422,12 +422,12 @@ hipError_t launch_one(cld_handle h, const ConvLayer& l, const ConvGeom& g, const
     if (use_wino1d(h, l, b_pad)) {
         ConvArgs w = a;
         w.wfrag = l.ufrag;
-        return launch_wino1d(w, l.g.l_in, l.c1_real, b_pad, s);
+        return launch_wino1d(w, l.g.l_in, b_pad, s);
     }
     return launch_conv(g, a, b_pad, s);
 }
 hipError_t launch_maybe_timed(cld_handle h, const ConvLayer& l, const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
-    const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && g.epi == EPI_GN_MISH && l.c_out == 256 &&
+    const bool timed = h->prof_on && g.l_in == 13 && g.ntaps == 5 && g.epi == EPI_GN_MISH && l.c_out == 256 && l.c1_real == 256 &&
                        (h->eval_counter % kProfStride) == 0;
     if (!timed) return launch_one(h, l, g, a, b_pad, s);
     if (h->prof_used + 2 > h->prof_ev.size()) {
@@ -458,6 +458,10 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
     if (h->launch_counter >= stop_after) return hipSuccess;
 #endif
     h->launch_counter += 2;
+    if (use_wino1d(h, la, b_pad) || use_wino1d(h, lb, b_pad)) {      // the k5 conv in its Winograd form; the 1x1 projection beside it stays a direct launch
+        hipError_t e = launch_maybe_timed(h, la, ga, aa, b_pad, s);
+        return e != hipSuccess ? e : launch_maybe_timed(h, lb, gb, ab, b_pad, s);
+    }
     if (ga.nwn == gb.nwn && ga.ks == gb.ks && conv_pair_supported(ga, gb)) return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
     hipError_t e = launch_maybe_timed(h, la, ga, aa, b_pad, s);
     return e != hipSuccess ? e : launch_maybe_timed(h, lb, gb, ab, b_pad, s);
@@ -809,7 +813,7 @@ int cld_finalize(cld_handle h, void* stream) {
                                     : ain       ? pack_conv_weights_split(wget, c_out, c1_pad + c2, ntaps)
                                                 : pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
         UP(l.wfrag, packed);
-        if (!split && !transposed && stride == 1 && ntaps == 5 && epi == EPI_GN_MISH && c2 == 0 && wino1d_supported(L_in, c1_real, c_out)) {
+        if (!split && !transposed && stride == 1 && ntaps == 5 && epi == EPI_GN_MISH && wino1d_supported(L_in, c1_real, c2, c_out)) {
             // F(4, 5) at the points {0, +-1, +-2, +-1/2, inf}: U[xi][ci][co] = sum_k G[xi][k] w[co][ci][k], in double
             static const double Gm[8][5] = {{-1, 0, 0, 0, 0},
                                             {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
@@ -824,7 +828,7 @@ int cld_finalize(cld_handle h, void* stream) {
                 for (int k = 0; k < 5; ++k) u += Gm[xi][k] * (double)W[((size_t)co * cin_real + ci) * kw + k];
                 return (float)u;
             };
-            std::vector<float> upacked = pack_conv_weights(uget, c_out, c1_real, 8);
+            std::vector<float> upacked = pack_conv_weights(uget, c_out, cin_real, 8);
             UP(l.ufrag, upacked);
         }
         UP(l.bias, *getw(h, wname + ".bias"));

@@ -74,9 +74,9 @@ bool conv_geom_supported(const ConvGeom& g);
 hipError_t launch_conv_pair(const ConvGeom& ga, const ConvArgs& a, const ConvGeom& gb, const ConvArgs& b, int b_pad, hipStream_t s);
 bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
 // Conv1d(k5, pad 2) + GroupNorm + Mish [+ vectors] [+ residual] by Winograd F(4, 5) (wino1d_kernels.hip): the 256 -> 256 launches at
-// L = 13; a.wfrag = G g in pack_conv_weights layout with the 8 transform points as taps; exact-fp32 activations only
-bool wino1d_supported(int l_in, int c_in, int c_out);
-hipError_t launch_wino1d(const ConvArgs& a, int l_in, int c_in, int b_pad, hipStream_t s);
+// L = 13 (256 -> 256, 128 -> 128, 128 -> 256, cat(256, 256) -> 128); a.wfrag = G g in pack_conv_weights layout with the 8 transform points as taps; exact-fp32 activations only
+bool wino1d_supported(int l_in, int c1, int c2, int c_out);      // c1 | c2: channels of the first | second (concatenated) source
+hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, hipStream_t s);
 void set_lds_floor(size_t bytes);      // experiments only: minimum dynamic LDS per conv launch (0 = off)
 
 // ---------------------------------------------------------------------------

@@ -62,53 +62,63 @@ __device__ __forceinline__ float mish1(float x) {      // conv_block.hip mish_f
     return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
-template <int L_, int C_>
+// CIN input channels in one tensor (CS == CIN) or in two of CS = CIN / 2 channels each (torch.cat of the skip, temporal.py:167: a second
+// buffer descriptor); COUT output channels in blocks of 64 per workgroup
+template <int L_, int CIN_, int CS_, int COUT_>
 struct W1Geo {
-    static constexpr int L = L_, C = C_;
-    static constexpr int TPA = (L + 3) / 4;            // tiles per agent
-    static constexpr int AG = 64 / TPA;                // agents per workgroup: 64 rows = four M-tiles
-    static constexpr int KC = 16, NCH = C / KC, NCB = C / 64, NTN = C / 16;
+    static constexpr int L = L_, CIN = CIN_, CS = CS_, COUT = COUT_;
+    static constexpr int TPA = (L + 3) / 4;            // tiles per agent: 4 at L = 13, 7 at L = 26
+    static constexpr int AG = TPA == 4 ? 16 : 8;       // agents per workgroup: 64 rows = four M-tiles (at L = 26 the last 8 rows are idle)
+    static constexpr int ROWS = AG * TPA;
+    static constexpr int KC = 16, NCH = CIN / KC, NC1 = CS / KC, NCB = COUT / 64, NTN = COUT / 16;
+    static constexpr int GS = COUT / 8;                // GroupNorm group: 32 channels = two waves, 16 = one, 8 = half of one
     static constexpr int VBUF = 8 * 64 * KC;           // floats per V image
-    static constexpr size_t LDS_BYTES = (2 * VBUF + 2 * 64) * sizeof(float);
-    static_assert(TPA == 4, "four tiles per agent: a quad of lanes is an agent");
-    static_assert(NCH % 2 == 0, "chunk pairs are unrolled");
+    static constexpr int XCH = 2 * 4 * 2 * 64;         // exchange scratch behind the images: [pass][wave][group of the wave][row]
+    static constexpr size_t LDS_BYTES = (2 * VBUF + XCH) * sizeof(float);
+    static_assert(TPA == 4 || TPA == 7, "L = 13 or 26");
+    static_assert(NCH % 2 == 0 && (CS == CIN || 2 * CS == CIN), "chunk pairs are unrolled; one source or two equal ones");
+    static_assert(GS == 32 || GS == 16 || GS == 8, "a group is two waves' channels, one wave's or half of one's");
+    static_assert(GS != 32 || TPA == 4, "the two-wave exchange is written for the quad layout");
+    static_assert(NCB == 1 || NCB == 2 || NCB == 4, "XCD-aware id mapping");
 };
 
 }  // namespace
 
-template <int L, int C>
+template <int L, int CIN, int CS, int COUT>
 __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map) {
-    typedef W1Geo<L, C> G;
+    typedef W1Geo<L, CIN, CS, COUT> G;
     extern __shared__ __attribute__((aligned(16))) float lds1[];
-    float* xch = lds1 + 2 * G::VBUF;                   // [2][4 waves][16 agents]: the GroupNorm sums of the two waves of a group meet here
+    float* xch = lds1 + 2 * G::VBUF;                   // GroupNorm sums meet here: two waves of a 32-channel group; the rows of an agent at L = 26
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int cb, grp;
     if (xcd_map) {                                     // ids x, x + 8, x + 16, x + 24: one agent group, one XCD, back to back
-        cb = (blockIdx.x >> 3) & 3;
-        grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
+        cb = (blockIdx.x >> 3) % G::NCB;
+        grp = (blockIdx.x / (8 * G::NCB)) * 8 + (blockIdx.x & 7);
     } else {
         cb = blockIdx.x % G::NCB;
         grp = blockIdx.x / G::NCB;
     }
     const int b0 = grp * G::AG;
 
-    // ---- staging role: row rs = (agent rs / 4, tile rs % 4), channels 4 c4 .. 4 c4 + 3 of the chunk ----
+    // ---- staging role: row rs = (agent rs / TPA, tile rs % TPA), channels 4 c4 .. 4 c4 + 3 of the chunk ----
     const int rs = tid >> 2, c4 = tid & 3;
-    const int total_bytes = b_pad * L * C * 4;
+    const int total_bytes = b_pad * L * CS * 4;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, total_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(CS == CIN ? p.x1 : p.x2), 0, total_bytes, 0x00020000);
     int voff[8];
     {
-        const int a = rs >> 2, t = rs & 3;
+        const int a = rs / G::TPA, t = rs % G::TPA;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int pos = 4 * t - 2 + i;
-            voff[i] = (pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * C + 4 * c4) * 4 : total_bytes;      // the zero padding: out of range reads 0
+            voff[i] = (rs < G::ROWS && pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * CS + 4 * c4) * 4 : total_bytes;      // the zero padding: out of range reads 0
         }
     }
     v4f d[8];
     auto patch_load = [&](const int i, const int c) {
-        d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff[i], c * (G::KC * 4), 0));
+        if (CS == CIN || c < G::NC1) d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff[i], c * (G::KC * 4), 0));
+        else d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx2, voff[i], (c - G::NC1) * (G::KC * 4), 0));
     };
     const int wofs = rs * 16 + ((((rs >> 2) & 3) ^ hsw1(c4)) << 2);
     // B^T d in four pieces (xi pairs share their even / odd halves), each stored as it is formed
@@ -191,12 +201,18 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         __syncthreads();
     }
 
-    // ---- epilogue.  Lane: channels n4 .. n4 + 3; M-tile m: agent b0 + 4 m + i16 / 4, tile t = i16 % 4, outputs at 4 t + o ----
+    // ---- epilogue.  Lane: channels n4 .. n4 + 3; M-tile m: row 16 m + i16 = (agent row / TPA, tile t = row % TPA), outputs at 4 t + o ----
     const int n4 = cb * 64 + 16 * wave + 4 * kk;
-    const int t = i16 & 3;
     const v4f bias = *reinterpret_cast<const v4f*>(p.bias + n4);
+    int al[4], tl[4];                                    // agent (within the workgroup) and tile of this lane's row of M-tile m
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int r = 16 * m + i16;
+        al[m] = G::TPA == 4 ? r >> 2 : r / G::TPA;
+        tl[m] = G::TPA == 4 ? r & 3 : r % G::TPA;
+    }
+    auto live = [&](const int m, const int o) { return (G::ROWS == 64 || 16 * m + i16 < G::ROWS) && 4 * tl[m] + o < L; };
     v4f Y[4][4];                                         // [m][o]
-    float s1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const v4f p12 = acc[1][m] + acc[2][m], m12 = acc[1][m] - acc[2][m];
@@ -206,76 +222,142 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         Y[m][1] = ((m12 + 2.0f * m34) + 0.5f * m56) + bias;
         Y[m][2] = ((p12 + 4.0f * p34) + 0.25f * p56) + bias;
         Y[m][3] = (((m12 + 8.0f * m34) + 0.125f * m56) + acc[7][m]) + bias;
-        float s = 0.f;
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (4 * t + o < L) s += (Y[m][o][0] + Y[m][o][1]) + (Y[m][o][2] + Y[m][o][3]);
-        s1[m] = agent_sum(s);
     }
-    // GroupNorm(32 channels x L rows per agent, eps 1e-5, biased variance, two passes; diffuser_helpers.py:61): the group's other
-    // half lives in wave w ^ 1
-    const float inv = 1.0f / (float)(32 * L);
-    if (kk == 0 && t == 0) {
+    // GroupNorm(GS channels x L rows per agent, eps 1e-5, biased variance, two passes; diffuser_helpers.py:61).  group_totals() turns a
+    // lane's partial sums (its 4 channels x its row's outputs) into the group's totals:
+    //   L = 13: an agent's four tiles are a quad of lanes -> DPP + permlane sums; a 32-channel group's other half lives in wave w ^ 1;
+    //   L = 26: the channel lanes by permlane sums, then the seven rows of the agent through LDS (wave-private: one wave holds whole
+    //           groups there), added in a fixed order.
+    constexpr bool PAIR = G::GS == 32;
+    const float inv = 1.0f / (float)(G::GS * L);
+    auto group_totals = [&](float (&v)[4], float* scratch) {
+        if constexpr (G::TPA == 4) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xch[wave * 16 + 4 * m + (i16 >> 2)] = s1[m];
-    }
-    __syncthreads();
+            for (int m = 0; m < 4; ++m) v[m] = agent_sum(v[m]);
+            if (PAIR) {
+                if (kk == 0 && (i16 & 3) == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) scratch[wave * 16 + 4 * m + (i16 >> 2)] = v[m];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] += scratch[(wave ^ 1) * 16 + 4 * m + (i16 >> 2)];
+            }
+        } else {
+            const int gsel = G::GS == 8 ? kk >> 1 : 0;
+            float* rowsum = scratch + (wave * 2 + gsel) * 64;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float sv = v[m];
+                const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, sv), __builtin_bit_cast(unsigned, sv), false, false);
+                const unsigned a16 = r16[0], b16 = r16[1];
+                sv = __builtin_bit_cast(float, a16) + __builtin_bit_cast(float, b16);
+                if (G::GS == 16) {
+                    const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, sv), __builtin_bit_cast(unsigned, sv), false, false);
+                    const unsigned a32 = r32[0], b32 = r32[1];
+                    sv = __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);
+                }
+                if ((kk & (G::GS == 8 ? 1 : 3)) == 0) rowsum[16 * m + i16] = sv;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed (a wave's LDS operations complete in order)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float tot = 0.f;
+                const int r0 = al[m] * G::TPA;
+#pragma unroll
+                for (int j = 0; j < G::TPA; ++j) tot += rowsum[(r0 + j) & 63];
+                v[m] = tot;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     float mean[4], s2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        mean[m] = (s1[m] + xch[(wave ^ 1) * 16 + 4 * m + (i16 >> 2)]) * inv;
-        float s = 0.f;
+        float sv = 0.f;
 #pragma unroll
         for (int o = 0; o < 4; ++o)
-            if (4 * t + o < L) {
-                const v4f dv = Y[m][o] - mean[m];
-                s += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
-            }
-        s2[m] = agent_sum(s);
+            if (live(m, o)) sv += (Y[m][o][0] + Y[m][o][1]) + (Y[m][o][2] + Y[m][o][3]);
+        mean[m] = sv;
     }
-    if (kk == 0 && t == 0) {
+    group_totals(mean, xch);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xch[64 + wave * 16 + 4 * m + (i16 >> 2)] = s2[m];
+    for (int m = 0; m < 4; ++m) {
+        mean[m] *= inv;
+        float sv = 0.f;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (live(m, o)) {
+                const v4f dv = Y[m][o] - mean[m];
+                sv += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+            }
+        s2[m] = sv;
     }
-    __syncthreads();
+    group_totals(s2, xch + G::XCH / 2);
     const v4f gam = *reinterpret_cast<const v4f*>(p.gamma + n4), bet = *reinterpret_cast<const v4f*>(p.beta + n4);
     const v4f tb = p.tbias ? *reinterpret_cast<const v4f*>(p.tbias + n4) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const int b = b0 + 4 * m + (i16 >> 2);
-        const float var = (s2[m] + xch[64 + (wave ^ 1) * 16 + 4 * m + (i16 >> 2)]) * inv;
-        const v4f sc = (1.0f / sqrtf(var + 1e-5f)) * gam;
+        if (G::ROWS < 64 && 16 * m + i16 >= G::ROWS) continue;
+        const int b = b0 + al[m];
+        const v4f sc = (1.0f / sqrtf(s2[m] * inv + 1e-5f)) * gam;
         v4f add = tb;
         if (p.cbias) add += *reinterpret_cast<const v4f*>(p.cbias + (size_t)b * p.cb_stride + n4);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const int pos = 4 * t + o;
+            const int pos = 4 * tl[m] + o;
             if (pos >= L) continue;
             const v4f x = (Y[m][o] - mean[m]) * sc + bet;
             v4f v = v4f{mish1(x[0]), mish1(x[1]), mish1(x[2]), mish1(x[3])} + add;
-            const size_t oidx = ((size_t)b * L + pos) * C + n4;
+            const size_t oidx = ((size_t)b * L + pos) * COUT + n4;
             if (p.res) v += *reinterpret_cast<const v4f*>(p.res + oidx);
             *reinterpret_cast<v4f*>(p.y + oidx) = v;
         }
     }
 }
 
-bool wino1d_supported(int l_in, int c_in, int c_out) { return l_in == 13 && c_in == 256 && c_out == 256; }
+// (L, C_in, channels per source, C_out): the k5 + GroupNorm + Mish layers of the L = 13 and L = 26 levels
+#define CLD_WINO1D_INSTANCES(X) \
+    X(13, 256, 256, 256)        \
+    X(13, 128, 128, 128)        \
+    X(13, 128, 128, 256)        \
+    X(13, 512, 256, 128)        \
+    X(26, 128, 128, 128)        \
+    X(26, 64, 64, 128)          \
+    X(26, 256, 128, 64)
 
-hipError_t launch_wino1d(const ConvArgs& a, int l_in, int c_in, int b_pad, hipStream_t s) {
-    if (!wino1d_supported(l_in, c_in, a.c_out) || b_pad < 16 || b_pad % 16 || a.x2 || a.c2 || a.res4_x) return hipErrorInvalidValue;
-    if ((long)b_pad * 13 * 256 * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
-    typedef W1Geo<13, 256> G;
-    auto kern = wino1d_conv_kernel<13, 256>;
+bool wino1d_supported(int l_in, int c1, int c2, int c_out) {
+#define X(L, CIN, CS, COUT) \
+    if (l_in == L && c1 == CS && c1 + c2 == CIN && c_out == COUT) return true;
+    CLD_WINO1D_INSTANCES(X)
+#undef X
+    return false;
+}
+
+template <int L, int CIN, int CS, int COUT>
+static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
+    typedef W1Geo<L, CIN, CS, COUT> G;
+    auto kern = wino1d_conv_kernel<L, CIN, CS, COUT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    if ((long)b_pad * L * CS * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
     const int groups = b_pad / G::AG;
     hipLaunchKernelGGL(kern, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
     return hipGetLastError();
+}
+
+hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, hipStream_t s) {
+    if (b_pad < 16 || b_pad % 16 || a.res4_x || a.c1_real != a.c1_pad || (a.c2 != 0) != (a.x2 != nullptr)) return hipErrorInvalidValue;
+#define X(L, CIN, CS, COUT) \
+    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_inst<L, CIN, CS, COUT>(a, b_pad, s);
+    CLD_WINO1D_INSTANCES(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 }  // namespace cld

@@ -16,6 +16,12 @@ L = [("b0.c0 4->64@52 (K folded)", 66560), ("b0.c1 64->64@52 (+res 1x1)", 106496
 # with the layer chains (conv_chain.hip, default from 1,024 rows): launches 0-4 and 24-29 are one launch each
 LC = [("chain: downs.0 (5 layers 64ch@52 -> 64@26)", sum(m for _, m in L[0:5]))] + L[5:24] + \
      [("chain: ups.1 2nd half + final_conv (6 layers)", sum(m for _, m in L[24:30])), ("head: DDPM update on eps [B,52,4]", 0)]
+# with the Winograd form of the k5 layers at L = 13 / 26 (wino1d_kernels.hip, default from 1,024 rows): a block's opening conv and its 1x1
+# residual projection are two launches (the pair kernel ran them as one)
+def split_pair(tag, mac, res_mac):
+    return [(tag.split("+res")[0] + " (k5, Winograd)" + tag.split("+res")[1], mac - res_mac), (tag.split("+res")[0].split(".")[0] + ".res 1x1" + tag.split("+res")[1], res_mac)]
+LW = [LC[0]] + split_pair(*LC[1], 212992) + LC[2:6] + split_pair(*LC[6], 425984) + LC[7:14] + split_pair(*LC[14], 851968) + LC[15:19] + \
+     split_pair(*LC[19], 425984) + LC[20:]
 path, B = sys.argv[1], int(sys.argv[2])
 rows = [r for r in csv.DictReader(open(path)) if "cld::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -30,7 +36,7 @@ evals = [ev for ev in evals if len(ev) == len(evals[-1])][-8:]
 assert evals, "no complete U-Net evaluation in the trace"
 nl = len(evals[-1])
 if any("chain_" in r["Kernel_Name"] for r in evals[-1]):
-    L = LC
+    L = LW if nl == len(LW) else LC
 labelled = nl == len(L)          # below ~2,048 rows some pairs run as two launches (their tilings differ): no per-launch FLOP then
 tot_t = 0.0
 tot_f = 2.0 * sum(m for _, m in L) * B
