@@ -36,11 +36,18 @@
 #define CLD_STORE_AUX 16
 #endif
 
+// A row's result must not depend on its place in the workgroup (tests: a shuffled batch reproduces its rows bit for bit).  The epilogue
+// is unrolled over the four M-tiles, and left to itself the compiler fuses a multiply-add in one unrolled copy and not in another
+// (scalar there, packed here): no implicit contraction in this file -- every fused multiply-add below is written as one.
+#pragma clang fp contract(off)
+
 namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 namespace {
+
+__device__ __forceinline__ v4f fma4(const v4f a, const float s, const v4f b) { return __builtin_elementwise_fma(a, v4f{s, s, s, s}, b); }      // a s + b
 
 __device__ __forceinline__ int hsw1(int k) { return ((k & 1) * 3) ^ (k >> 1); }      // wino_kernels.hip hsw
 
@@ -58,8 +65,8 @@ __device__ __forceinline__ float agent_sum(float s) {
 }
 __device__ __forceinline__ float mish1(float x) {      // conv_block.hip mish_f
     const float e = __expf(fminf(x, 30.0f));
-    const float n = e * (e + 2.0f);
-    return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
+    const float n = __builtin_fmaf(e, e, 2.0f * e);
+    return (x * n) * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
 // CIN input channels in one tensor (CS == CIN) or in two of CS = CIN / 2 channels each (torch.cat of the skip, temporal.py:167: a second
@@ -126,17 +133,17 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         float* vb = lds1 + buf * G::VBUF + wofs;
         auto st = [&](const int xi, const v4f v) { *reinterpret_cast<v4f*>(vb + xi * (64 * 16)) = v; };
         if (k == 0) {
-            const v4f e = (d[2] + d[6]) - 4.25f * d[4], o = (d[1] + d[5]) - 4.25f * d[3];
+            const v4f e = fma4(d[4], -4.25f, d[2] + d[6]), o = fma4(d[3], -4.25f, d[1] + d[5]);
             st(1, e + o); st(2, e - o);
         } else if (k == 1) {
-            const v4f e = (0.25f * d[2] - 1.25f * d[4]) + d[6], o = (0.5f * d[1] - 2.5f * d[3]) + 2.0f * d[5];
+            const v4f e = fma4(d[2], 0.25f, fma4(d[4], -1.25f, d[6])), o = fma4(d[1], 0.5f, fma4(d[3], -2.5f, 2.0f * d[5]));
             st(3, e + o); st(4, e - o);
         } else if (k == 2) {
-            const v4f e = (4.0f * d[2] - 5.0f * d[4]) + d[6], o = (2.0f * d[1] - 2.5f * d[3]) + 0.5f * d[5];
+            const v4f e = fma4(d[2], 4.0f, fma4(d[4], -5.0f, d[6])), o = fma4(d[1], 2.0f, fma4(d[3], -2.5f, 0.5f * d[5]));
             st(5, e + o); st(6, e - o);
         } else {
-            st(0, (d[6] - d[0]) + 5.25f * (d[2] - d[4]));
-            st(7, (d[7] - d[1]) + 5.25f * (d[3] - d[5]));
+            st(0, fma4(d[2] - d[4], 5.25f, d[6] - d[0]));
+            st(7, fma4(d[3] - d[5], 5.25f, d[7] - d[1]));
         }
     };
 
@@ -219,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         const v4f p34 = acc[3][m] + acc[4][m], m34 = acc[3][m] - acc[4][m];
         const v4f p56 = acc[5][m] + acc[6][m], m56 = acc[5][m] - acc[6][m];
         Y[m][0] = ((acc[0][m] + p12) + (p34 + p56)) + bias;
-        Y[m][1] = ((m12 + 2.0f * m34) + 0.5f * m56) + bias;
-        Y[m][2] = ((p12 + 4.0f * p34) + 0.25f * p56) + bias;
-        Y[m][3] = (((m12 + 8.0f * m34) + 0.125f * m56) + acc[7][m]) + bias;
+        Y[m][1] = fma4(m56, 0.5f, fma4(m34, 2.0f, m12)) + bias;
+        Y[m][2] = fma4(p56, 0.25f, fma4(p34, 4.0f, p12)) + bias;
+        Y[m][3] = (fma4(m56, 0.125f, fma4(m34, 8.0f, m12)) + acc[7][m]) + bias;
     }
     // GroupNorm(GS channels x L rows per agent, eps 1e-5, biased variance, two passes; diffuser_helpers.py:61).  group_totals() turns a
     // lane's partial sums (its 4 channels x its row's outputs) into the group's totals:
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         for (int o = 0; o < 4; ++o)
             if (live(m, o)) {
                 const v4f dv = Y[m][o] - mean[m];
-                sv += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+                sv += __builtin_fmaf(dv[0], dv[0], dv[1] * dv[1]) + __builtin_fmaf(dv[2], dv[2], dv[3] * dv[3]);
             }
         s2[m] = sv;
     }
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         for (int o = 0; o < 4; ++o) {
             const int pos = 4 * tl[m] + o;
             if (pos >= L) continue;
-            const v4f x = (Y[m][o] - mean[m]) * sc + bet;
+            const v4f x = __builtin_elementwise_fma(Y[m][o] - mean[m], sc, bet);
             v4f v = v4f{mish1(x[0]), mish1(x[1]), mish1(x[2]), mish1(x[3])} + add;
             const size_t oidx = ((size_t)b * L + pos) * COUT + n4;
             if (p.res) v += *reinterpret_cast<const v4f*>(p.res + oidx);

@@ -42,6 +42,10 @@
 #define WINO_EXP 0
 #endif
 
+// no implicit multiply-add contraction: the epilogue is unrolled over the two M-tiles, and a tile's result must not depend on which copy
+// computed it (wino1d_kernels.hip)
+#pragma clang fp contract(off)
+
 namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs p) {
                 const int oy = 2 * ty + dy, ox = 2 * tx + dx;
                 if ((HIN & 1) && (oy >= HIN || ox >= HIN)) continue;
                 const size_t o = (((size_t)a * HIN + oy) * HIN + ox) * G::C + n4;
-                v4f v = Y[dy][dx] * sc + sh;
+                v4f v = __builtin_elementwise_fma(Y[dy][dx], sc, sh);
                 if (p.res) v += *reinterpret_cast<const v4f*>(p.res + o);
                 if (p.relu) v = v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                 *reinterpret_cast<v4f*>(p.y + o) = v;

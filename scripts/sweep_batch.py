@@ -7,7 +7,9 @@ from cld_amd.engine import Engine
 dev = torch.device("cuda:0")
 prec = os.environ.get("CLD_SWEEP_PRECISION", "f32")
 e = Engine(100, dev, precision=prec); e.load_state_dict(synth.make_unet_weights(0)); e.finalize()
-print("precision", prec)
+form = os.environ.get("CLD_SWEEP_CONV5")          # direct | winograd: force the form of the k5 layers at L = 13 / 26 (default: by rows)
+if form: e.force_kernel("conv5", form)
+print("precision", prec, "conv5", form or "auto")
 for B in [int(a) for a in sys.argv[1:]] or [64, 256, 512, 1024, 2048, 4096, 8192]:
     g = torch.Generator(device=dev); g.manual_seed(B)
     x = torch.randn(B, 52, 4, device=dev, generator=g); c = torch.randn(B, 256, device=dev, generator=g)
