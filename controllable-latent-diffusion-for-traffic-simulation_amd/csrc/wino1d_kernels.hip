@@ -45,6 +45,31 @@ namespace cld {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+#ifdef CLD_STAMPS
+// diagnostic build: in-kernel cycle stamps (never compiled into the shipped library); scripts/wino1d_stamps.py reads them
+#define W1STAMP(k)                                                                                 \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (p.stamps && tid == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                          \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define W1STAMP_RT(k)                                                                              \
+    do {                                                                                           \
+        if (p.stamps && tid == 0) {                                                                \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+            p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                          \
+        }                                                                                          \
+    } while (0)
+#else
+#define W1STAMP(k) do {} while (0)
+#define W1STAMP_RT(k) do {} while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ v4f fma4(const v4f a, const float s, const v4f b) { return __builtin_elementwise_fma(a, v4f{s, s, s, s}, b); }      // a s + b
@@ -107,6 +132,14 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         grp = blockIdx.x / G::NCB;
     }
     const int b0 = grp * G::AG;
+    W1STAMP(0);
+    W1STAMP_RT(8);
+#ifdef CLD_STAMPS
+    if (p.stamps && tid == 0) {      // where the dispatcher put this workgroup: HW_ID (wave slot, SIMD, CU, SH, SE) and XCC_ID
+        p.stamps[(size_t)blockIdx.x * 16 + 10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        p.stamps[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 
     // ---- staging role: row rs = (agent rs / TPA, tile rs % TPA), channels 4 c4 .. 4 c4 + 3 of the chunk ----
     const int rs = tid >> 2, c4 = tid & 3;
@@ -172,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
 #pragma unroll
     for (int k = 0; k < 4; ++k) transform_piece(k, 0);
     __syncthreads();
+    W1STAMP(1);
 
     // one chunk: 8 xi x 4 M-tiles x 4 MFMAs.  Fragments run two (xi, M-tile) items ahead of their MFMAs (a rolling window of three);
     // the next chunk's rows are requested during xi = 0, 1 and transformed during xi = 4 .. 7
@@ -206,7 +240,9 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         const bool more = c + 2 < G::NCH;
         mfma_block(1, c + 1, more);
         __syncthreads();
+        if (c == 0) W1STAMP(5);
     }
+    W1STAMP(2);
 
     // ---- epilogue.  Lane: channels n4 .. n4 + 3; M-tile m: row 16 m + i16 = (agent row / TPA, tile t = row % TPA), outputs at 4 t + o ----
     const int n4 = cb * 64 + 16 * wave + 4 * kk;
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         s2[m] = sv;
     }
     group_totals(s2, xch + G::XCH / 2);
+    W1STAMP(3);
     const v4f gam = *reinterpret_cast<const v4f*>(p.gamma + n4), bet = *reinterpret_cast<const v4f*>(p.beta + n4);
     const v4f tb = p.tbias ? *reinterpret_cast<const v4f*>(p.tbias + n4) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -322,6 +359,8 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
             *reinterpret_cast<v4f*>(p.y + oidx) = v;
         }
     }
+    W1STAMP(4);
+    W1STAMP_RT(9);
 }
 
 // (L, C_in, channels per source, C_out): the k5 + GroupNorm + Mish layers of the L = 13 and L = 26 levels

@@ -9,7 +9,8 @@ SRC, DST = os.path.join(ROOT, "gpurun_out", "r03"), os.path.join(ROOT, "profiles
 os.makedirs(DST, exist_ok=True)
 
 for f in ("bench_n1.json", "bench_n1_configs1.json", "bench_n1_configs3.json", "bench_n1_configs4_shard.json", "bench_n2_gloo_rehearsal.json",
-          "batch_sweep.txt", "guide_time.txt", "unet_B64.txt", "unet_B1024.txt", "unet_B2048.txt", "unet_B4096.txt", "chain_check.txt", "collision_time.txt"):
+          "batch_sweep.txt", "batch_sweep_direct_form.txt", "ctx_time_1024.txt", "wino1d_stamps_4096.txt", "ctx_clock_mfma_busy.txt",
+          "guide_time.txt", "unet_B64.txt", "unet_B1024.txt", "unet_B2048.txt", "unet_B4096.txt", "chain_check.txt", "collision_time.txt"):
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, f))
 shutil.copy(os.path.join(SRC, "kstats", "bench_kernel_stats.csv"), os.path.join(DST, "kernel_stats_bench_configs2_steps1_warmup1.csv"))
