@@ -88,10 +88,22 @@ __device__ __forceinline__ float agent_sum(float s) {
     const unsigned a32 = r32[0], b32 = r32[1];
     return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);
 }
-__device__ __forceinline__ float mish1(float x) {      // conv_block.hip mish_f
-    const float e = __expf(fminf(x, 30.0f));
-    const float n = __builtin_fmaf(e, e, 2.0f * e);
-    return (x * n) * __builtin_amdgcn_rcpf(n + 2.0f);
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+// Mish = x n / (n + 2), n = e^x (e^x + 2) (conv_block.hip mish_f: one v_exp_f32 and one v_rcp_f32 per value), on register pairs so that
+// everything but the exponential, the reciprocal and the clamp is a packed fp32 instruction (two values per issue slot)
+__device__ __forceinline__ v2f mish2(const v2f x) {
+    const v2f c = v2f{fminf(x[0], 30.0f), fminf(x[1], 30.0f)} * v2f{1.4426950408889634f, 1.4426950408889634f};
+    const v2f e = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
+    const v2f two = {2.0f, 2.0f};
+    const v2f n = e * (e + two);
+    const v2f d = n + two;
+    const v2f r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return (x * n) * r;
+}
+__device__ __forceinline__ v4f mish4(const v4f x) {
+    const v2f lo = mish2(v2f{x[0], x[1]}), hi = mish2(v2f{x[2], x[3]});
+    return v4f{lo[0], lo[1], hi[0], hi[1]};
 }
 
 // CIN input channels in one tensor (CS == CIN) or in two of CS = CIN / 2 channels each (torch.cat of the skip, temporal.py:167: a second
@@ -341,22 +353,35 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     W1STAMP(3);
     const v4f gam = *reinterpret_cast<const v4f*>(p.gamma + n4), bet = *reinterpret_cast<const v4f*>(p.beta + n4);
     const v4f tb = p.tbias ? *reinterpret_cast<const v4f*>(p.tbias + n4) : v4f{0.f, 0.f, 0.f, 0.f};
+    // output and residual through buffer descriptors: one 32-bit offset per (M-tile, lane), the four outputs of a tile at immediate
+    // distances, a dead output (past the end of the agent, an idle row) at an out-of-range offset -- dropped by the range check: no
+    // 64-bit address arithmetic and no branch per store
+    const int ybytes = b_pad * L * COUT * 4;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, ybytes, 0x00020000);
+    const bool has_res = p.res != nullptr;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        if (G::ROWS < 64 && 16 * m + i16 >= G::ROWS) continue;
         const int b = b0 + al[m];
+        const bool rowok = G::ROWS == 64 || 16 * m + i16 < G::ROWS;
+        const int obase = (((b * L + 4 * tl[m]) * COUT) + n4) * 4;
+        int ooff[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) ooff[o] = (rowok && 4 * tl[m] + o < L) ? obase + o * (COUT * 4) : ybytes;
+        v4f rv[4];
+        if (has_res) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rv[o] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsr, ooff[o], 0, 0));
+        }
         const v4f sc = (1.0f / sqrtf(s2[m] * inv + 1e-5f)) * gam;
         v4f add = tb;
-        if (p.cbias) add += *reinterpret_cast<const v4f*>(p.cbias + (size_t)b * p.cb_stride + n4);
+        if (p.cbias && rowok) add += *reinterpret_cast<const v4f*>(p.cbias + (size_t)b * p.cb_stride + n4);
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const int pos = 4 * tl[m] + o;
-            if (pos >= L) continue;
             const v4f x = __builtin_elementwise_fma(Y[m][o] - mean[m], sc, bet);
-            v4f v = v4f{mish1(x[0]), mish1(x[1]), mish1(x[2]), mish1(x[3])} + add;
-            const size_t oidx = ((size_t)b * L + pos) * COUT + n4;
-            if (p.res) v += *reinterpret_cast<const v4f*>(p.res + oidx);
-            *reinterpret_cast<v4f*>(p.y + oidx) = v;
+            v4f v = mish4(x) + add;
+            if (has_res) v += rv[o];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rsy, ooff[o], 0, 0);
         }
     }
     W1STAMP(4);
@@ -391,7 +416,7 @@ static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if ((long)b_pad * L * CS * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
+    if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
     const int groups = b_pad / G::AG;
     hipLaunchKernelGGL(kern, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
     return hipGetLastError();

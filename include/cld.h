@@ -444,7 +444,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
                                * per layer (conv_block.hip), CLD_FORM_CHAIN the LDS-resident layer chains (conv_chain.hip) */
 #define CLD_KERNEL_CONTEXT 4  /* the 3x3 / stride-1 convolutions of the ContextEncoder: CLD_FORM_AUTO / CLD_FORM_WINOGRAD Winograd F(2x2, 3x3)
                                * (wino_kernels.hip), CLD_FORM_DIRECT the implicit-GEMM kernel the other convolutions use */
-#define CLD_KERNEL_CONV5 5    /* the 256 -> 256 Conv1d(k5) + GroupNorm + Mish launches of a U-Net evaluation (exact-fp32 handles): CLD_FORM_AUTO
+#define CLD_KERNEL_CONV5 5    /* the Conv1d(k5) + GroupNorm + Mish launches of the L = 13 / 26 levels of a U-Net evaluation (exact-fp32 handles): CLD_FORM_AUTO
                                * by batch size, CLD_FORM_DIRECT conv_block.hip, CLD_FORM_WINOGRAD Winograd F(4, 5) (wino1d_kernels.hip) */
 #define CLD_FORM_AUTO 0       /* by batch size (default) */
 #define CLD_FORM_VALU 1       /* one or two agents per workgroup, gate rows in registers */
