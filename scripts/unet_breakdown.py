@@ -30,7 +30,7 @@ names = [r["Kernel_Name"] for r in rows]
 ends = [i for i, n in enumerate(names) if "cld::head_kernel" in n]
 evals = []
 for a, e in zip(ends[:-1], ends[1:]):
-    ev = [r for r in rows[a + 1:e + 1] if any(k in r["Kernel_Name"] for k in ("conv_block_kernel", "conv_pair_kernel", "cld::head_kernel", "chain_", "wino1d_conv_kernel"))]
+    ev = [r for r in rows[a + 1:e + 1] if any(k in r["Kernel_Name"] for k in ("conv_block_kernel", "conv_pair_kernel", "cld::head_kernel", "chain_", "wino1d_"))]
     evals.append(ev)
 evals = [ev for ev in evals if len(ev) == len(evals[-1])][-8:]
 assert evals, "no complete U-Net evaluation in the trace"
