@@ -418,6 +418,8 @@ constexpr int kWino1dMinRows = 768;       // launch sets of at least this many r
                                           // launch is a few workgroups' serial MFMA chain and the direct form's small tiles spread it wider)
 bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
     if (!l.ufrag || h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_DIRECT) return false;
+    const long widest = l.c1_real > l.c_out ? l.c1_real : l.c_out;      // the Winograd kernel addresses its tensors with 32-bit byte offsets
+    if ((long)b_pad * l.g.l_in * widest * 4 >= (1L << 31)) return false;
     return h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_WINOGRAD || b_pad >= kWino1dMinRows;
 }
 hipError_t launch_one(cld_handle h, const ConvLayer& l, const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {

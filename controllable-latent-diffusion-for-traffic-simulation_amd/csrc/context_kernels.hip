@@ -32,7 +32,10 @@ __device__ __forceinline__ v4f cbuf_load16(__amdgpu_buffer_rsrc_t r, int voff, i
 // =============================================================================================
 namespace stem {
 constexpr int CIN = 34, HIN = 224, HO = 112, COUT = 64;
-constexpr int TR = 2;                     // output rows per workgroup
+#ifndef STEM_TR
+#define STEM_TR 2
+#endif
+constexpr int TR = STEM_TR;               // output rows per workgroup
 constexpr int PRW = 2 * TR + 5;           // input rows of the strip: 9
 constexpr int RS = 233;                   // LDS row stride (floats): odd, so taps that wrap to the next kernel row hit other banks
 constexpr int SMT = TR * HO / 16;         // 14 M-tiles, 7 per output row
@@ -46,7 +49,7 @@ constexpr int BUF = PRW * RS;             // floats per strip image
 // of k-steps 4qg..4qg+3; scale/shift [64]: folded BatchNorm; y [B,112,112,64] NHWC.
 // three workgroups per CU (<= 168 VGPRs: the plane batch is 2 deep for that) so that one workgroup's plane loads and
 // barriers hide behind the MFMAs of the others: 1.44 -> 1.25 ms structured, 6.59 -> 6.42 ms dense per 256 agents
-__global__ __launch_bounds__(256, 3) void stem_conv_kernel(const float* __restrict__ image, const float* __restrict__ wq,
+__global__ __launch_bounds__(256, stem::TR == 2 ? 3 : 2) void stem_conv_kernel(const float* __restrict__ image, const float* __restrict__ wq,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        float* __restrict__ y, int B) {
     using namespace stem;
@@ -195,23 +198,26 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const float* __restri
                 }
             }
         } else {
-            // sparse plane: only the column blocks that see a non-zero value (both rows of the block: M-tiles cb, cb + 7)
+            // sparse plane: only the column blocks that see a non-zero value (every row of the block: M-tiles cb, cb + 7, ...)
 #pragma unroll
             for (int cb = 0; cb < 7; ++cb) {
                 if (!((blocks >> cb) & 1)) continue;
-                const int imm0 = ib + (32 * cb) * 4, imm1 = imm0 + 2 * RS * 4;
-                float a0 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm0);
-                float a1 = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm1);
+                const int imm0 = ib + (32 * cb) * 4;
+                float a[TR];
+#pragma unroll
+                for (int r = 0; r < TR; ++r) a[r] = *reinterpret_cast<const float*>(ldsb + qoff[0] + imm0 + r * 2 * RS * 4);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const float bv = bq[q >> 2][q & 3];
-                    const float c0v = a0, c1v = a1;
+                    float cv[TR];
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) cv[r] = a[r];
                     if (q + 1 < NQ) {
-                        a0 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm0);
-                        a1 = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm1);
+#pragma unroll
+                        for (int r = 0; r < TR; ++r) a[r] = *reinterpret_cast<const float*>(ldsb + qoff[q + 1 < NQ ? q + 1 : q] + imm0 + r * 2 * RS * 4);
                     }
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0v, bv, acc[cb], 0, 0, 0);
-                    acc[cb + 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1v, bv, acc[cb + 7], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < TR; ++r) acc[cb + 7 * r] = __builtin_amdgcn_mfma_f32_16x16x4f32(cv[r], bv, acc[cb + 7 * r], 0, 0, 0);
                 }
             }
         }
