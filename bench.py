@@ -269,7 +269,7 @@ def main():
                 split = eng.precision == "f16x2"      # 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi) per algorithmic product
                 peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
                 traffic = pmc_traffic(rows) if not split else (None, None)
-                wino = not split and rows >= 768          # csrc/cld_api.hip kWino1dMinRows: the Winograd F(4, 5) form of these launches
+                wino = not split and rows >= 384          # csrc/cld_api.hip kWino1dMinRows: the Winograd F(4, 5) form of these launches
                 what = ("Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; 7 launches per U-Net evaluation, all with 256 input channels "
                         "-- every 10th evaluation timed")
                 roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

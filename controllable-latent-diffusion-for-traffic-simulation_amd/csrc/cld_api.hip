@@ -413,9 +413,10 @@ ConvArgs make_args(cld_handle h, const ConvLayer& l, const float* x1, const floa
 // One conv launch; launches of the dominant kernel shape (k5 + GroupNorm + Mish block producing 256 channels at L = 13) are
 // bracketed by HIP events in every kProfStride-th U-Net evaluation while profiling is on: an event pair costs ~2 us of stream
 // time, and bracketing all 800 such launches of a 100-step sample call slowed the timed region itself by 5 %.
-constexpr int kWino1dMinRows = 768;       // launch sets of at least this many rows take the Winograd form of the k5 layers at L = 13 / 26 (100-step sample,
-                                          // direct / Winograd: 60.7 / 78.6 ms at 512 rows, 89.5 / 85.3 at 768, 102.3 / 89.3 at 1,024, 189.8 / 136.7 at 2,048; below, the
-                                          // launch is a few workgroups' serial MFMA chain and the direct form's small tiles spread it wider)
+constexpr int kWino1dMinRows = 384;       // launch sets of at least this many rows take the Winograd form of the k5 layers at L = 13 / 26 (100-step sample,
+                                          // direct / Winograd: 38.7 / 53.6 ms at 256 rows, 60.1 / 57.4 at 384, 60.7 / 58.7 at 512, 89.5 / 76.0 at 768, 102.3 / 80.2 at
+                                          // 1,024, 189.8 / 134.3 at 2,048; launches of fewer than 512 whole items run as half items, wino1d_kernels.hip; below 384
+                                          // rows a launch is a few workgroups' serial MFMA chain and the direct form's small tiles spread it wider)
 bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
     if (!l.ufrag || h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_DIRECT) return false;
     const long widest = l.c1_real > l.c_out ? l.c1_real : l.c_out;      // the Winograd kernel addresses its tensors with 32-bit byte offsets

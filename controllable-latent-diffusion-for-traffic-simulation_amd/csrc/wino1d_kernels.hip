@@ -32,6 +32,9 @@
 // Workgroup id -> (agent group, channel block) keeps the four channel blocks of an agent group on one XCD (they stage the same rows).
 #include "cld_kernels.h"
 
+#ifndef WINO1D_HALVES_BELOW
+#define WINO1D_HALVES_BELOW 512
+#endif
 #ifndef CLD_STORE_AUX
 #define CLD_STORE_AUX 16
 #endif
@@ -128,22 +131,14 @@ struct W1Geo {
 
 }  // namespace
 
-template <int L, int CIN, int CS, int COUT>
-__global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map) {
+// One item: NM M-tiles (4 = a whole agent group, 2 = half of one) x the 64 output channels of block cb, agents b0 ..
+template <int L, int CIN, int CS, int COUT, int NM>
+__device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, const int cb, const int b0, float* lds1) {
     typedef W1Geo<L, CIN, CS, COUT> G;
-    extern __shared__ __attribute__((aligned(16))) float lds1[];
+    constexpr int ROWS = G::ROWS * NM / 4;             // live rows of the item (at L = 26 the rest of its last M-tile idles)
     float* xch = lds1 + 2 * G::VBUF;                   // GroupNorm sums meet here: two waves of a 32-channel group; the rows of an agent at L = 26
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int cb, grp;
-    if (xcd_map) {                                     // ids x, x + 8, x + 16, x + 24: one agent group, one XCD, back to back
-        cb = (blockIdx.x >> 3) % G::NCB;
-        grp = (blockIdx.x / (8 * G::NCB)) * 8 + (blockIdx.x & 7);
-    } else {
-        cb = blockIdx.x % G::NCB;
-        grp = blockIdx.x / G::NCB;
-    }
-    const int b0 = grp * G::AG;
     W1STAMP(0);
     W1STAMP_RT(8);
 #ifdef CLD_STAMPS
@@ -164,17 +159,20 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int pos = 4 * t - 2 + i;
-            voff[i] = (rs < G::ROWS && pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * CS + 4 * c4) * 4 : total_bytes;      // the zero padding: out of range reads 0
+            voff[i] = (rs < ROWS && pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * CS + 4 * c4) * 4 : total_bytes;      // the zero padding: out of range reads 0
         }
     }
     v4f d[8];
+    const bool stager = wave < NM;                     // (wave-uniform) rows 16 w .. 16 w + 15 are staged by wave w
     auto patch_load = [&](const int i, const int c) {
+        if (!stager) return;
         if (CS == CIN || c < G::NC1) d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff[i], c * (G::KC * 4), 0));
         else d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx2, voff[i], (c - G::NC1) * (G::KC * 4), 0));
     };
     const int wofs = rs * 16 + ((((rs >> 2) & 3) ^ hsw1(c4)) << 2);
     // B^T d in four pieces (xi pairs share their even / odd halves), each stored as it is formed
     auto transform_piece = [&](const int k, const int buf) {
+        if (!stager) return;
         float* vb = lds1 + buf * G::VBUF + wofs;
         auto st = [&](const int xi, const v4f v) { *reinterpret_cast<v4f*>(vb + xi * (64 * 16)) = v; };
         if (k == 0) {
@@ -203,11 +201,11 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff, item * (G::NTN * 1024) + wsoff, 0));
     };
 
-    v4f acc[8][4];
+    v4f acc[8][NM];
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[xi][m] = v4f{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < NM; ++m) acc[xi][m] = v4f{0.f, 0.f, 0.f, 0.f};
     v4f bq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bq[i] = wload(i);
@@ -219,11 +217,11 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     __syncthreads();
     W1STAMP(1);
 
-    // one chunk: 8 xi x 4 M-tiles x 4 MFMAs.  Fragments run two (xi, M-tile) items ahead of their MFMAs (a rolling window of three);
+    // one chunk: 8 xi x NM M-tiles x 4 MFMAs.  Fragments run two (xi, M-tile) items ahead of their MFMAs (a rolling window of three);
     // the next chunk's rows are requested during xi = 0, 1 and transformed during xi = 4 .. 7
     auto mfma_block = [&](const int buf, const int c, const bool stage) {
         const int bo = buf * (G::VBUF * 4);
-        auto frag = [&](const int it) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + (it >> 2) * 4096 + (it & 3) * 1024); };
+        auto frag = [&](const int it) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + (it / NM) * 4096 + (it % NM) * 1024); };
         v4f ar[3];
         ar[0] = frag(0);
         ar[1] = frag(1);
@@ -232,10 +230,10 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
             const v4f bcur = bq[xi & 3];
             bq[xi & 3] = wload(c * 8 + xi + 4);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int it = 4 * xi + m;
-                if (it + 2 < 32) ar[(it + 2) % 3] = frag(it + 2);
-                if (stage && xi < 2) { patch_load(4 * xi + m, c + 1); }
+            for (int m = 0; m < NM; ++m) {
+                const int it = NM * xi + m;
+                if (it + 2 < 8 * NM) ar[(it + 2) % 3] = frag(it + 2);
+                if (stage && it < 8) patch_load(it, c + 1);
                 if (stage && xi >= 4 && m == 1) transform_piece(xi - 4, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -259,17 +257,17 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     // ---- epilogue.  Lane: channels n4 .. n4 + 3; M-tile m: row 16 m + i16 = (agent row / TPA, tile t = row % TPA), outputs at 4 t + o ----
     const int n4 = cb * 64 + 16 * wave + 4 * kk;
     const v4f bias = *reinterpret_cast<const v4f*>(p.bias + n4);
-    int al[4], tl[4];                                    // agent (within the workgroup) and tile of this lane's row of M-tile m
+    int al[NM], tl[NM];                                   // agent (within the workgroup) and tile of this lane's row of M-tile m
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NM; ++m) {
         const int r = 16 * m + i16;
         al[m] = G::TPA == 4 ? r >> 2 : r / G::TPA;
         tl[m] = G::TPA == 4 ? r & 3 : r % G::TPA;
     }
-    auto live = [&](const int m, const int o) { return (G::ROWS == 64 || 16 * m + i16 < G::ROWS) && 4 * tl[m] + o < L; };
-    v4f Y[4][4];                                         // [m][o]
+    auto live = [&](const int m, const int o) { return (ROWS == 16 * NM || 16 * m + i16 < ROWS) && 4 * tl[m] + o < L; };
+    v4f Y[NM][4];                                         // [m][o]
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NM; ++m) {
         const v4f p12 = acc[1][m] + acc[2][m], m12 = acc[1][m] - acc[2][m];
         const v4f p34 = acc[3][m] + acc[4][m], m34 = acc[3][m] - acc[4][m];
         const v4f p56 = acc[5][m] + acc[6][m], m56 = acc[5][m] - acc[6][m];
@@ -285,24 +283,24 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     //           groups there), added in a fixed order.
     constexpr bool PAIR = G::GS == 32;
     const float inv = 1.0f / (float)(G::GS * L);
-    auto group_totals = [&](float (&v)[4], float* scratch) {
+    auto group_totals = [&](float (&v)[NM], float* scratch) {
         if constexpr (G::TPA == 4) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) v[m] = agent_sum(v[m]);
+            for (int m = 0; m < NM; ++m) v[m] = agent_sum(v[m]);
             if (PAIR) {
                 if (kk == 0 && (i16 & 3) == 0) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) scratch[wave * 16 + 4 * m + (i16 >> 2)] = v[m];
+                    for (int m = 0; m < NM; ++m) scratch[wave * 16 + 4 * m + (i16 >> 2)] = v[m];
                 }
                 __syncthreads();
 #pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] += scratch[(wave ^ 1) * 16 + 4 * m + (i16 >> 2)];
+                for (int m = 0; m < NM; ++m) v[m] += scratch[(wave ^ 1) * 16 + 4 * m + (i16 >> 2)];
             }
         } else {
             const int gsel = G::GS == 8 ? kk >> 1 : 0;
             float* rowsum = scratch + (wave * 2 + gsel) * 64;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < NM; ++m) {
                 float sv = v[m];
                 const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, sv), __builtin_bit_cast(unsigned, sv), false, false);
                 const unsigned a16 = r16[0], b16 = r16[1];
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
             __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed (a wave's LDS operations complete in order)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < NM; ++m) {
                 float tot = 0.f;
                 const int r0 = al[m] * G::TPA;
 #pragma unroll
@@ -327,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
             __builtin_amdgcn_wave_barrier();
         }
     };
-    float mean[4], s2[4];
+    float mean[NM], s2[NM];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NM; ++m) {
         float sv = 0.f;
 #pragma unroll
         for (int o = 0; o < 4; ++o)
@@ -338,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     }
     group_totals(mean, xch);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NM; ++m) {
         mean[m] *= inv;
         float sv = 0.f;
 #pragma unroll
@@ -361,9 +359,9 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, ybytes, 0x00020000);
     const bool has_res = p.res != nullptr;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NM; ++m) {
         const int b = b0 + al[m];
-        const bool rowok = G::ROWS == 64 || 16 * m + i16 < G::ROWS;
+        const bool rowok = ROWS == 16 * NM || 16 * m + i16 < ROWS;
         const int obase = (((b * L + 4 * tl[m]) * COUT) + n4) * 4;
         int ooff[4];
 #pragma unroll
@@ -386,6 +384,27 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
     }
     W1STAMP(4);
     W1STAMP_RT(9);
+}
+
+// Workgroup id -> item.  Whole items (a 16-agent group at L = 13, 8 agents at L = 26) when there are at least 512 of them -- two per CU;
+// below that every group is split into two half items (two M-tiles each: twice the U traffic per MFMA, but a second wave on every SIMD:
+// at 1,024 rows 256 whole items leave every CU with one workgroup).  ids x, x + 8, x + 16, x + 24 (whole) resp. 2 x the same (halves) are
+// the channel blocks of one agent group: one XCD, back to back.
+template <int L, int CIN, int CS, int COUT>
+__global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map, const int halves) {
+    typedef W1Geo<L, CIN, CS, COUT> G;
+    extern __shared__ __attribute__((aligned(16))) float lds1[];
+    const int e = halves ? blockIdx.x >> 1 : blockIdx.x;
+    int cb, grp;
+    if (xcd_map) {
+        cb = (e >> 3) % G::NCB;
+        grp = (e / (8 * G::NCB)) * 8 + (e & 7);
+    } else {
+        cb = e % G::NCB;
+        grp = e / G::NCB;
+    }
+    if (!halves) wino1d_item<L, CIN, CS, COUT, 4>(p, b_pad, cb, grp * G::AG, lds1);
+    else wino1d_item<L, CIN, CS, COUT, 2>(p, b_pad, cb, grp * G::AG + (blockIdx.x & 1) * (G::AG / 2), lds1);
 }
 
 // (L, C_in, channels per source, C_out): the k5 + GroupNorm + Mish layers of the L = 13 and L = 26 levels
@@ -417,8 +436,9 @@ static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s
         attr_done = true;
     }
     if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
-    const int groups = b_pad / G::AG;
-    hipLaunchKernelGGL(kern, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
+    const int groups = b_pad / G::AG, nfull = groups * G::NCB;
+    const int halves = nfull < WINO1D_HALVES_BELOW ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(nfull << halves), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0, halves);
     return hipGetLastError();
 }
 
