@@ -195,6 +195,24 @@ def test_guidance_struct_matches_header():
     assert [m for m in re.findall(r"\b(curr_states|target_speed|loss_scale|lr|perturb_th|optimizer|speed_limit|acc_limit|speed_limit_scale|acc_limit_scale|target_pos|target_time|target_pos_scale|ext_grad|apply_output|no_intermediate|final_lr|final_perturb_th|final_optimizer|grad_steps|final_grad_steps|guide_clean|collision|map_collision);", body)] == [n for n, _ in g._fields_]
 
 
+def test_force_kernel_tables_match_header():
+    """`Engine.force_kernel(which, form)` goes through the name tables of `_lib`; the numbers are include/cld.h's CLD_KERNEL_* / CLD_FORM_*
+    (the tests force every formulation of a kernel through them: a drifted number would silently test another form)."""
+    import re
+    from cld_amd import _lib
+    text = open(os.path.join(ROOT, "include", "cld.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(CLD_(?:KERNEL|FORM)_[A-Z0-9_]+)\s+(\d+)", text)}
+    kernels = {"guide": "GUIDE", "decode": "DECODE", "encode": "ENCODE", "unet": "UNET", "context": "CONTEXT", "conv5": "CONV5"}
+    assert set(_lib.KERNELS) == set(kernels)
+    for name, macro in kernels.items():
+        assert _lib.KERNELS[name] == defs["CLD_KERNEL_" + macro], name
+    forms = {"auto": "AUTO", "valu": "VALU", "mfma": "MFMA", "quad": "MFMA_QUAD", "layers": "LAYERS", "chain": "CHAIN", "chain1": "CHAIN_TILE1",
+             "chain4": "CHAIN_TILE4", "direct": "DIRECT", "winograd": "WINOGRAD"}
+    assert set(_lib.FORMS) == set(forms)
+    for name, macro in forms.items():
+        assert _lib.FORMS[name] == defs["CLD_FORM_" + macro], name
+
+
 def test_timers_keep_the_reference_surface():
     """cld_amd.timer.Timers: tic / toc / timed / __str__ as src/tbsim/utils/timer.py:41-64 (host clock path, no GPU)."""
     import time as _t
