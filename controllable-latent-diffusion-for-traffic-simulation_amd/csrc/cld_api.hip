@@ -414,7 +414,7 @@ ConvArgs make_args(cld_handle h, const ConvLayer& l, const float* x1, const floa
 // bracketed by HIP events in every kProfStride-th U-Net evaluation while profiling is on: an event pair costs ~2 us of stream
 // time, and bracketing all 800 such launches of a 100-step sample call slowed the timed region itself by 5 %.
 constexpr int kWino1dMinRows = 384;       // launch sets of at least this many rows take the Winograd form of the k5 layers at L = 13 / 26 (100-step sample,
-                                          // direct / Winograd: 38.7 / 53.6 ms at 256 rows, 60.1 / 57.4 at 384, 60.7 / 58.7 at 512, 89.5 / 76.0 at 768, 102.3 / 80.2 at
+                                          // direct / Winograd: 38.7 / 48.0 ms at 256 rows, 60.1 / 51.8 at 384, 60.7 / 53.3 at 512, 89.5 / 70.8 at 768, 102.3 / 75.1 at
                                           // 1,024, 189.8 / 134.3 at 2,048; launches of fewer than 512 whole items run as half items, wino1d_kernels.hip; below 384
                                           // rows a launch is a few workgroups' serial MFMA chain and the direct form's small tiles spread it wider)
 bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {

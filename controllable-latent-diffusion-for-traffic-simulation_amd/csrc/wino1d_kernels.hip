@@ -148,8 +148,12 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
     }
 #endif
 
-    // ---- staging role: row rs = (agent rs / TPA, tile rs % TPA), channels 4 c4 .. 4 c4 + 3 of the chunk ----
-    const int rs = tid >> 2, c4 = tid & 3;
+    // ---- staging role: row rs = (agent rs / TPA, tile rs % TPA); a whole item: 64 rows x four channels of the chunk per thread (16-byte
+    //      loads); a half item: 32 rows x TWO channels (8-byte loads), so that all four waves stage there as well -- with the 16-byte map
+    //      waves 2, 3 of a half item had nothing to stage and waited at every chunk barrier for waves 0, 1 ----
+    constexpr int SW = NM == 4 ? 4 : 2;                // channels per staging thread
+    typedef float vS __attribute__((ext_vector_type(SW)));
+    const int rs = NM == 4 ? tid >> 2 : tid >> 3, cq = NM == 4 ? tid & 3 : tid & 7;
     const int total_bytes = b_pad * L * CS * 4;
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, total_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(CS == CIN ? p.x1 : p.x2), 0, total_bytes, 0x00020000);
@@ -159,34 +163,42 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int pos = 4 * t - 2 + i;
-            voff[i] = (rs < ROWS && pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * CS + 4 * c4) * 4 : total_bytes;      // the zero padding: out of range reads 0
+            voff[i] = (rs < ROWS && pos >= 0 && pos < L) ? (((b0 + a) * L + pos) * CS + SW * cq) * 4 : total_bytes;      // the zero padding: out of range reads 0
         }
     }
-    v4f d[8];
-    const bool stager = wave < NM;                     // (wave-uniform) rows 16 w .. 16 w + 15 are staged by wave w
-    auto patch_load = [&](const int i, const int c) {
-        if (!stager) return;
-        if (CS == CIN || c < G::NC1) d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, voff[i], c * (G::KC * 4), 0));
-        else d[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx2, voff[i], (c - G::NC1) * (G::KC * 4), 0));
+    vS d[8];
+    auto ld = [&](const __amdgpu_buffer_rsrc_t r, const int vo, const int so) {
+        if constexpr (SW == 4) return __builtin_bit_cast(vS, __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0));
+        else return __builtin_bit_cast(vS, __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, 0));
     };
-    const int wofs = rs * 16 + ((((rs >> 2) & 3) ^ hsw1(c4)) << 2);
+    auto patch_load = [&](const int i, const int c) {
+        if (CS == CIN || c < G::NC1) d[i] = ld(rsx, voff[i], c * (G::KC * 4));
+        else d[i] = ld(rsx2, voff[i], (c - G::NC1) * (G::KC * 4));
+    };
+    const int c4 = NM == 4 ? cq : cq >> 1;              // the 16-byte slot of the row
+    const int wofs = rs * 16 + ((((rs >> 2) & 3) ^ hsw1(c4)) << 2) + (NM == 4 ? 0 : (cq & 1) * 2);
+    auto fmaS = [](const vS a, const float sc, const vS b) {
+        vS sv;
+#pragma unroll
+        for (int j = 0; j < SW; ++j) sv[j] = sc;
+        return __builtin_elementwise_fma(a, sv, b);
+    };
     // B^T d in four pieces (xi pairs share their even / odd halves), each stored as it is formed
     auto transform_piece = [&](const int k, const int buf) {
-        if (!stager) return;
         float* vb = lds1 + buf * G::VBUF + wofs;
-        auto st = [&](const int xi, const v4f v) { *reinterpret_cast<v4f*>(vb + xi * (64 * 16)) = v; };
+        auto st = [&](const int xi, const vS v) { *reinterpret_cast<vS*>(vb + xi * (64 * 16)) = v; };
         if (k == 0) {
-            const v4f e = fma4(d[4], -4.25f, d[2] + d[6]), o = fma4(d[3], -4.25f, d[1] + d[5]);
+            const vS e = fmaS(d[4], -4.25f, d[2] + d[6]), o = fmaS(d[3], -4.25f, d[1] + d[5]);
             st(1, e + o); st(2, e - o);
         } else if (k == 1) {
-            const v4f e = fma4(d[2], 0.25f, fma4(d[4], -1.25f, d[6])), o = fma4(d[1], 0.5f, fma4(d[3], -2.5f, 2.0f * d[5]));
+            const vS e = fmaS(d[2], 0.25f, fmaS(d[4], -1.25f, d[6])), o = fmaS(d[1], 0.5f, fmaS(d[3], -2.5f, 2.0f * d[5]));
             st(3, e + o); st(4, e - o);
         } else if (k == 2) {
-            const v4f e = fma4(d[2], 4.0f, fma4(d[4], -5.0f, d[6])), o = fma4(d[1], 2.0f, fma4(d[3], -2.5f, 0.5f * d[5]));
+            const vS e = fmaS(d[2], 4.0f, fmaS(d[4], -5.0f, d[6])), o = fmaS(d[1], 2.0f, fmaS(d[3], -2.5f, 0.5f * d[5]));
             st(5, e + o); st(6, e - o);
         } else {
-            st(0, fma4(d[2] - d[4], 5.25f, d[6] - d[0]));
-            st(7, fma4(d[3] - d[5], 5.25f, d[7] - d[1]));
+            st(0, fmaS(d[2] - d[4], 5.25f, d[6] - d[0]));
+            st(7, fmaS(d[3] - d[5], 5.25f, d[7] - d[1]));
         }
     };
 
@@ -394,7 +406,7 @@ template <int L, int CIN, int CS, int COUT>
 __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map, const int halves) {
     typedef W1Geo<L, CIN, CS, COUT> G;
     extern __shared__ __attribute__((aligned(16))) float lds1[];
-    const int e = halves ? blockIdx.x >> 1 : blockIdx.x;
+    const int e = halves ? blockIdx.x >> 1 : blockIdx.x, half = halves ? (int)(blockIdx.x & 1) : -1;
     int cb, grp;
     if (xcd_map) {
         cb = (e >> 3) % G::NCB;
@@ -403,8 +415,8 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         cb = e % G::NCB;
         grp = e / G::NCB;
     }
-    if (!halves) wino1d_item<L, CIN, CS, COUT, 4>(p, b_pad, cb, grp * G::AG, lds1);
-    else wino1d_item<L, CIN, CS, COUT, 2>(p, b_pad, cb, grp * G::AG + (blockIdx.x & 1) * (G::AG / 2), lds1);
+    if (half < 0) wino1d_item<L, CIN, CS, COUT, 4>(p, b_pad, cb, grp * G::AG, lds1);
+    else wino1d_item<L, CIN, CS, COUT, 2>(p, b_pad, cb, grp * G::AG + half * (G::AG / 2), lds1);
 }
 
 // (L, C_in, channels per source, C_out): the k5 + GroupNorm + Mish layers of the L = 13 and L = 26 levels
