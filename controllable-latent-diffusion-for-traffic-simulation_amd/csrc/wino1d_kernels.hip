@@ -449,7 +449,10 @@ static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s
     }
     if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
     const int groups = b_pad / G::AG, nfull = groups * G::NCB;
-    const int halves = nfull < WINO1D_HALVES_BELOW ? 1 : 0;
+    // whole items when they fill generations of 512 (two workgroups per CU); halves below one generation and when the last generation
+    // would be at most half full (752 whole items are two rounds, 1,504 halves one and a half)
+    const int tail = nfull % WINO1D_HALVES_BELOW;
+    const int halves = (nfull < WINO1D_HALVES_BELOW || (tail != 0 && tail <= WINO1D_HALVES_BELOW / 2)) ? 1 : 0;
     hipLaunchKernelGGL(kern, dim3(nfull << halves), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0, halves);
     return hipGetLastError();
 }
