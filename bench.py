@@ -272,26 +272,31 @@ def main():
                 wino = not split and rows >= 384          # csrc/cld_api.hip kWino1dMinRows: the Winograd F(4, 5) form of these launches
                 what = ("Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; 7 launches per U-Net evaluation, all with 256 input channels "
                         "-- every 10th evaluation timed")
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],
+                # `achieved` / `frac`: FLOP the MFMA pipe EXECUTED (counted by the library for the form each timed launch took:
+                # cld_profile_read_executed) / time / peak -- a utilisation, <= 1 by construction.  The Winograd F(4, 5) form computes the
+                # same sums with 8 x 4 MFMA k-steps per agent and channel pair instead of 5 x 13, so the rate counted on the direct
+                # form's multiplies (SURVEY 8d's unit) can pass the pipe's peak: it is reported under its own name, never as `frac`.
+                ex_flop = eng.profile_read_executed()[0]
+                ex_ach = ex_flop / (ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(ex_ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(ex_ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],
                         "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                        else "v_mfma_f32_16x16x4_f32 dense peak"),
                         "kernel": ("wino1d_conv_kernel<13,256,256,256> (%s)" % what if wino else
                                    "conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0,0> (%s; tiling picked by the rows per launch)"
                                    % ("4,1" if rows >= 2048 else ("4,2" if rows >= 1024 else "2,2"), what)),
                         "agents_per_launch": rows, "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
-                        "flop_per_launch": flop / launches}
-                if wino:
-                    # `achieved` counts the ALGORITHMIC work (2 x rows x 5 taps x 256 x 256 per launch, the direct form); the
-                    # kernel computes the same sums by Winograd F(4, 5) with 8 x 4 MFMA k-steps per agent and channel pair instead of
-                    # 5 x 13, so the algorithmic rate can pass the pipe's peak.  `executed` is what the MFMA pipe really did.
-                    ex = rows * 4 * 8 * 2.0 * 256 * 256
-                    ex_ach = ex / (ms * 1e-3 / launches) / 1e12
-                    roof["executed"] = {"flop_per_launch": ex, "achieved": round(ex_ach, 2), "frac": round(ex_ach / peak, 4),
-                                        "note": "MFMA FLOP issued per launch: 4 tiles x 8 transform points per agent (Winograd F(4, 5): 2.03x "
-                                                "fewer multiplies than the 5 x 13 row-taps `achieved` is counted on); frac = MFMA pipe utilisation"}
+                        "executed_flop_per_launch": ex_flop / launches,
+                        "achieved_basis": "MFMA FLOP issued per launch as reported by the library for the form it chose "
+                                          "(cld_profile_read_executed), / HIP-event time of the same launches",
+                        "direct_form_flop_per_launch": flop / launches,
+                        "direct_form_equivalent_tflops": round(ach, 2),
+                        "multiply_reduction": round(flop / ex_flop, 4)}
+        ex_t, ev_alg, ev_ex, ev_n = eng.profile_read_executed()
+        ev_rows = (B + 15) // 16 * 16          # agents of this rank; a CFG evaluation carries both passes of each
+        evalinfo = {"alg_flop_per_agent": ev_alg / ev_rows, "exec_flop_per_agent": ev_ex / ev_rows, "launches": ev_n}
         units = B_total * n * steps * max(1, closed)
-        return {"dt": dt, "B": B, "B_total": B_total, "units": units, "roof": roof, "even": even}
+        return {"dt": dt, "B": B, "B_total": B_total, "units": units, "roof": roof, "even": even, "eval": evalinfo}
 
     def describe(wl, name, custom):
         c = "BASELINE configs[%d]" % wl["idx"] + ((" with overrides (%s)" % ", ".join(custom)) if custom else "")
@@ -330,8 +335,15 @@ def main():
                    "unet_passes_per_step": passes, "guidance_gradient": bool(wl["guide"]), "sim_steps_per_bench_step": wl["closed"],
                    "weights": "random init (synth seed 0)"},
         "scenes_per_s": round((wl["scenes"] if wl["sharded"] else wl["scenes"] * world) * args.steps / r["dt"], 2),
-        "unet_tflops_effective": round(value * FLOP_PER_STEP_AGENT * passes / 1e12, 2),
-        "roofline_whole_path_frac": round(value * FLOP_PER_STEP_AGENT * passes / 1e12 / peak_tf, 4),
+        # whole path: FLOP the MFMAs of ALL launches of a denoising step's U-Net evaluation execute (per agent, both CFG passes; counted
+        # by the library per launch and form) x units/s / peak: the share of the fp32-MFMA pipe the whole job keeps busy (guidance,
+        # decode and the host loop are in the time, not in the FLOP).  <= 1 by construction.
+        "roofline_whole_path_frac": round(value * r["eval"]["exec_flop_per_agent"] / 1e12 / peak_tf, 4),
+        "unet_executed_tflops": round(value * r["eval"]["exec_flop_per_agent"] / 1e12, 2),
+        "unet_launches_per_evaluation": r["eval"]["launches"],
+        # the same rate counted on the direct form's multiplies (119,232,512 FLOP per U-Net pass and agent); may exceed the
+        # pipe's peak where Winograd forms run -- a speed-up figure, not a utilisation
+        "direct_form_equivalent_tflops": round(value * FLOP_PER_STEP_AGENT * passes / 1e12, 2),
     }
     if distributed:
         anchor = None
@@ -372,7 +384,8 @@ def main():
         pk = PEAK_F16_MFMA_TFLOPS / 3.0 if precision == "f16x2" else PEAK_F32_MFMA_TFLOPS
         d = {"workload": describe(w2, wname, sorted(over)), "value": round(v2, 1), "unit": "step·agent/s",
              "ms_per_step": round(r2["dt"] / steps * 1e3, 3), "steps": steps, "agents": r2["B_total"],
-             "roofline_whole_path_frac": round(v2 * FLOP_PER_STEP_AGENT * p2 / 1e12 / pk, 4)}
+             "roofline_whole_path_frac": round(v2 * r2["eval"]["exec_flop_per_agent"] / 1e12 / pk, 4),
+             "direct_form_equivalent_tflops": round(v2 * FLOP_PER_STEP_AGENT * p2 / 1e12, 2)}
         if note:
             d["note"] = note
         return d

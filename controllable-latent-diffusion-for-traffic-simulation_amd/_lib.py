@@ -106,6 +106,7 @@ SIGNATURES = {
     "cld_world_step": (C.c_int, [_P, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P]),
     "cld_profile_enable": (C.c_int, [_P, C.c_int32]),
     "cld_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "cld_profile_read_executed": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "cld_set_stride": (C.c_int, [_P, C.c_int32]),
     "cld_debug_lds_floor": (C.c_int, [_P, C.c_size_t]),
     "cld_debug_force_kernel": (C.c_int, [_P, C.c_int32, C.c_int32]),

@@ -85,6 +85,11 @@ struct cld_handle_s {
     std::vector<hipEvent_t> prof_ev;     // pairs (start, stop)
     size_t prof_used = 0;
     double prof_flop = 0.0;              // algorithmic FLOP of the timed launches
+    double prof_exec_flop = 0.0;         // FLOP their MFMAs executed in the form each launch took (Winograd F(4, 5): 8 x 4 k-steps per agent
+                                         // and channel pair instead of 5 x 13)
+    // the same two counts over ALL launches of the most recent U-Net evaluation (cld_profile_read_executed)
+    double eval_alg_flop = 0.0, eval_exec_flop = 0.0;
+    int eval_launches = 0;
     // diagnostic (-DCLD_STAMPS builds): launch index within a U-Net evaluation that receives the stamp buffer
     unsigned long long* stamp_buf = nullptr;
     int stamp_layer = -1, launch_counter = 0;
@@ -423,7 +428,24 @@ bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
     if ((long)b_pad * l.g.l_in * widest * 4 >= (1L << 31)) return false;
     return h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_WINOGRAD || b_pad >= kWino1dMinRows;
 }
+// FLOP a conv launch stands for (2 x output rows x K x N over the real channels) and FLOP its MFMAs execute in the form
+// the launch takes: the direct form pads the 4-channel latent's K to (tap, channel) = 20; the Winograd form runs 8 GEMMs over
+// wino1d_gemm_rows() rows (64 per item, idle rows of the L = 26 items included) x C_in x C_out
+void count_flop(cld_handle h, const ConvLayer& l, int b_pad, double* alg, double* exec) {
+    const double cin = (double)(l.c1_real + l.c2);
+    *alg = 2.0 * (double)b_pad * l.g.lm * (l.g.ntaps * cin) * l.c_out;
+    if (use_wino1d(h, l, b_pad)) *exec = 2.0 * (double)wino1d_gemm_rows(l.g.l_in, b_pad) * 8.0 * cin * l.c_out;
+    else *exec = 2.0 * (double)b_pad * l.g.lm * (l.g.padc ? 20.0 : (double)(l.g.ntaps * (l.c1_pad + l.c2))) * l.c_out;
+}
+void count_launch(cld_handle h, const ConvLayer& l, int b_pad) {
+    double alg, exec;
+    count_flop(h, l, b_pad, &alg, &exec);
+    h->eval_alg_flop += alg;
+    h->eval_exec_flop += exec;
+    h->eval_launches++;
+}
 hipError_t launch_one(cld_handle h, const ConvLayer& l, const ConvGeom& g, const ConvArgs& a, int b_pad, hipStream_t s) {
+    count_launch(h, l, b_pad);
     if (use_wino1d(h, l, b_pad)) {
         ConvArgs w = a;
         w.wfrag = l.ufrag;
@@ -449,7 +471,10 @@ hipError_t launch_maybe_timed(cld_handle h, const ConvLayer& l, const ConvGeom& 
     if (e != hipSuccess) return e;
     e = hipEventRecord(h->prof_ev[h->prof_used + 1], s);
     h->prof_used += 2;
-    h->prof_flop += 2.0 * (double)b_pad * l.g.lm * (double)(l.g.ntaps * (l.c1_pad + l.c2)) * l.c_out;
+    double alg, exec;
+    count_flop(h, l, b_pad, &alg, &exec);
+    h->prof_flop += alg;
+    h->prof_exec_flop += exec;
     return e;
 }
 
@@ -467,7 +492,12 @@ hipError_t run_pair(cld_handle h, const ConvLayer& la, const ConvArgs& aa, const
         hipError_t e = launch_maybe_timed(h, la, ga, aa, b_pad, s);
         return e != hipSuccess ? e : launch_maybe_timed(h, lb, gb, ab, b_pad, s);
     }
-    if (ga.nwn == gb.nwn && ga.ks == gb.ks && conv_pair_supported(ga, gb)) return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
+    if (ga.nwn == gb.nwn && ga.ks == gb.ks && conv_pair_supported(ga, gb)) {
+        count_launch(h, la, b_pad);
+        count_launch(h, lb, b_pad);
+        h->eval_launches--;          // one launch for the two layers
+        return launch_conv_pair(ga, aa, gb, ab, b_pad, s);
+    }
     hipError_t e = launch_maybe_timed(h, la, ga, aa, b_pad, s);
     return e != hipSuccess ? e : launch_maybe_timed(h, lb, gb, ab, b_pad, s);
 }
@@ -515,6 +545,8 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
     float* const* b = w.buf;
     h->launch_counter = 0;
     h->eval_counter++;
+    h->eval_alg_flop = h->eval_exec_flop = 0.0;
+    h->eval_launches = 0;
     set_lds_floor(h->lds_floor);
     hipError_t e;
 #define RC(...) do { e = run_conv(h, __VA_ARGS__, w.cb, tbr, b_pad, s); if (e != hipSuccess) return e; } while (0)
@@ -554,6 +586,9 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ca.keep = b[2]; ca.y = b[6];
         ca.stamps = (h->stamp_buf && h->stamp_layer == 0) ? h->stamp_buf : nullptr;
         h->launch_counter += 5;
+        h->eval_alg_flop += 2.0 * b_pad * 52.0 * 64 * (20 + 3 * 320) + 2.0 * b_pad * 26.0 * 64 * 192 + 2.0 * b_pad * 52.0 * 64 * 4;
+        h->eval_exec_flop += chain_head_exec_flop(b_pad, chain_tile(h, b_pad));
+        h->eval_launches++;
         e = launch_chain_head(ca, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
     } else {
@@ -613,6 +648,9 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
             h->upd_fused = true;
         }
         h->launch_counter += 6;
+        h->eval_alg_flop += 2.0 * b_pad * 26.0 * 64 * (3 * 320) + 2.0 * b_pad * 52.0 * 64 * 128 + 2.0 * b_pad * 52.0 * 64 * 320 + 2.0 * b_pad * 52.0 * 4 * 64;
+        h->eval_exec_flop += chain_tail_exec_flop(b_pad, chain_tile(h, b_pad));
+        h->eval_launches++;
         e = launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
         h->eps_in_buf7 = true;
@@ -726,6 +764,7 @@ int cld_profile_enable(cld_handle h, int32_t on) {
     h->prof_used = 0;
     h->eval_counter = -1;
     h->prof_flop = 0.0;
+    h->prof_exec_flop = 0.0;
     return CLD_OK;
 }
 
@@ -741,6 +780,16 @@ int cld_profile_read(cld_handle h, double* total_ms, int64_t* launches, double* 
     if (total_ms) *total_ms = ms;
     if (launches) *launches = (int64_t)(h->prof_used / 2);
     if (total_flop) *total_flop = h->prof_flop;
+    return CLD_OK;
+}
+
+int cld_profile_read_executed(cld_handle h, double* timed_executed_flop, double* eval_algorithmic_flop, double* eval_executed_flop,
+                              int32_t* eval_launches) {
+    if (!h) return CLD_ERR_ARG;
+    if (timed_executed_flop) *timed_executed_flop = h->prof_exec_flop;
+    if (eval_algorithmic_flop) *eval_algorithmic_flop = h->eval_alg_flop;
+    if (eval_executed_flop) *eval_executed_flop = h->eval_exec_flop;
+    if (eval_launches) *eval_launches = h->eval_launches;
     return CLD_OK;
 }
 

@@ -77,6 +77,7 @@ bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
 // L = 13 (256 -> 256, 128 -> 128, 128 -> 256, cat(256, 256) -> 128); a.wfrag = G g in pack_conv_weights layout with the 8 transform points as taps; exact-fp32 activations only
 bool wino1d_supported(int l_in, int c1, int c2, int c_out);      // c1 | c2: channels of the first | second (concatenated) source
 hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, hipStream_t s);
+long wino1d_gemm_rows(int l_in, int b_pad);     // GEMM rows (64 per item, idle ones included) a launch runs its 8 transform-domain products over
 void set_lds_floor(size_t bytes);      // experiments only: minimum dynamic LDS per conv launch (0 = off)
 
 // ---------------------------------------------------------------------------
@@ -131,6 +132,9 @@ struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_c
     unsigned long long seed, step_salt;
 };
 hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile /* 4 | 1 */, hipStream_t s);
+// FLOP the MFMAs of a chain launch execute (2,048 per v_mfma_f32_16x16x4_f32, padded M-tiles and N columns included)
+double chain_head_exec_flop(int b_pad, int agents_per_tile);
+double chain_tail_exec_flop(int b_pad, int agents_per_tile);
 
 // ---------------------------------------------------------------------------
 // small kernels (misc_kernels.hip)

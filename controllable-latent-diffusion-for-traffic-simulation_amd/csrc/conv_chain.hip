@@ -411,6 +411,12 @@ static hipError_t launch_chain_head_inst(const ChainHeadArgs& a, int b_pad, hipS
     hipLaunchKernelGGL(chain_head_kernel<AG>, dim3(b_pad / AG), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
+// MFMAs per wave and workgroup: the latent's conv (5 per M-tile), three k5 layers (20 (tap, group) iterations x 4 per M-tile), the
+// stride-2 conv (12 iterations x 4 per M-tile of the L = 26 output)
+template <int AG> static constexpr double head_mfma_per_wave() { return 5.0 * Geo<52, AG>::NMT + 3 * 80.0 * Geo<52, AG>::NMT + 48.0 * Geo<26, AG>::NMT; }
+double chain_head_exec_flop(int b_pad, int agents_per_tile) {
+    return agents_per_tile == 1 ? head_mfma_per_wave<1>() * 4 * 2048.0 * b_pad : head_mfma_per_wave<4>() * 4 * 2048.0 * (b_pad / 4);
+}
 hipError_t launch_chain_head(const ChainHeadArgs& a, int b_pad, int agents_per_tile, hipStream_t s) {
     return agents_per_tile == 1 ? launch_chain_head_inst<1>(a, b_pad, s) : launch_chain_head_inst<4>(a, b_pad, s);
 }
@@ -608,6 +614,14 @@ static hipError_t launch_chain_tail_inst(const ChainTailArgs& a, int b_pad, hipS
     if (b_pad % AG) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chain_tail_kernel<AG>, dim3(b_pad / AG), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
+}
+// three k5 layers at L = 26, the two parity convolutions (8 iterations x 4 per M-tile each), final_conv.0 at L = 52, final_conv.1 (16 per
+// M-tile, shared between the four waves)
+template <int AG> static constexpr double tail_mfma_per_wave() {
+    return 3 * 80.0 * Geo<26, AG>::NMT + 2 * 32.0 * Geo<26, AG>::NMT + 80.0 * Geo<52, AG>::NMT + 4.0 * Geo<52, AG>::NMT;
+}
+double chain_tail_exec_flop(int b_pad, int agents_per_tile) {
+    return agents_per_tile == 1 ? tail_mfma_per_wave<1>() * 4 * 2048.0 * b_pad : tail_mfma_per_wave<4>() * 4 * 2048.0 * (b_pad / 4);
 }
 hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile, hipStream_t s) {
     return agents_per_tile == 1 ? launch_chain_tail_inst<1>(a, b_pad, s) : launch_chain_tail_inst<4>(a, b_pad, s);

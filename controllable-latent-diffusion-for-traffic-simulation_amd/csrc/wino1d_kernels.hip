@@ -437,6 +437,8 @@ bool wino1d_supported(int l_in, int c1, int c2, int c_out) {
     return false;
 }
 
+long wino1d_gemm_rows(int l_in, int b_pad) { return l_in == 13 ? 4L * b_pad : 8L * b_pad; }      // 16 / 8 agents per 64-row item
+
 template <int L, int CIN, int CS, int COUT>
 static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     typedef W1Geo<L, CIN, CS, COUT> G;

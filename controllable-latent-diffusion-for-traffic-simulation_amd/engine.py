@@ -684,3 +684,11 @@ class Engine:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         self._check(self.lib.cld_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(fl)), "cld_profile_read")
         return ms.value, n.value, fl.value
+
+    def profile_read_executed(self):
+        """-> (MFMA FLOP executed by the launches profile_read timed, in the form each took; algorithmic FLOP, executed MFMA
+        FLOP and launch count of the most recent U-Net evaluation)."""
+        ex, ea, ee, nl = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        self._check(self.lib.cld_profile_read_executed(self._h, C.byref(ex), C.byref(ea), C.byref(ee), C.byref(nl)),
+                    "cld_profile_read_executed")
+        return ex.value, ea.value, ee.value, nl.value

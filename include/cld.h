@@ -421,6 +421,13 @@ int cld_world_step(cld_handle h, const float* traj, const float* centroid, const
  * number of launches and their algorithmic FLOP (2 * rows * K * N); enable(…, 1) resets. */
 int cld_profile_enable(cld_handle h, int32_t on);
 int cld_profile_read(cld_handle h, double* total_ms /*HOST*/, int64_t* launches /*HOST*/, double* total_flop /*HOST*/);
+/* What the MFMA pipe executed, counted by the library for the form each launch actually took (no reference counterpart):
+ * `timed_executed_flop` = FLOP issued by the MFMAs of the launches cld_profile_read timed (the Winograd F(4, 5) form of a k5 layer
+ * runs 8 transform-domain GEMMs over 4 tiles per agent instead of 5 taps over 13 rows: 2.03x fewer than total_flop counts);
+ * `eval_*` = the algorithmic FLOP, the executed MFMA FLOP and the number of kernel launches of the handle's most recent U-Net
+ * evaluation (all of its launches, layer chains included).  bench.py's roofline.frac is executed FLOP / time / peak. */
+int cld_profile_read_executed(cld_handle h, double* timed_executed_flop /*HOST*/, double* eval_algorithmic_flop /*HOST*/,
+                              double* eval_executed_flop /*HOST*/, int32_t* eval_launches /*HOST*/);
 
 /* Diagnostic builds only (-DCLD_STAMPS; a no-op in the shipped library): conv launch number `layer`
  * (0..36) of every following U-Net evaluation writes 16 u64 cycle stamps per workgroup into `buf`. */

@@ -604,9 +604,7 @@ def agent_collision_loss(x: Tensor, extent: Tensor, world_from_agent: Tensor, cu
         pos_w, yaw_w = torch.where(m, pos_w, pos_w.detach()), torch.where(m, yaw_w, yaw_w.detach())
     rad = extent[:, 1] / 2.0
     cmin, cmax = -(extent[:, 0] / 2.0) + rad, (extent[:, 0] / 2.0) - rad
-    frac = torch.linspace(0.0, 1.0, num_disks, dtype=x.dtype)
     cx = torch.stack([torch.linspace(float(cmin[b]), float(cmax[b]), num_disks) for b in range(B)]).to(x.dtype)   # as init_disks builds them
-    del frac
     cent = pos_w.unsqueeze(-2) + cx.view(B, 1, 1, num_disks, 1) * torch.cat([torch.cos(yaw_w), torch.sin(yaw_w)], dim=-1).unsqueeze(-2)   # [B,N,T,D,2]
     pen_d = rad.view(B, 1) + rad.view(1, B) + buffer_dist
     same = (scene_index.view(B, 1) == scene_index.view(1, B)) & ~torch.eye(B, dtype=torch.bool)
