@@ -35,7 +35,9 @@ struct ConvLayer {
     ConvGeom g{};        // kc / nwn / ks are filled per launch by pick_tiling()
     bool has_a = false, has_b = false;   // which tilings have a kernel instance
     float *wfrag = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;
-    float* ufrag = nullptr;   // Winograd-domain filters G g of a layer wino1d_kernels.hip can run (exact-fp32 handles)
+    float* ufrag = nullptr;   // Winograd-domain filters G g of a k5 layer that has a Winograd form (exact-fp32 handles): as a launch of its own
+                              // (wino1d_kernels.hip: wino_launch) or inside the layer chains (chain_wino.hip: the 64 -> 64 layers at L = 52 / 26)
+    bool wino_launch = false;
     int c_out = 0, c1_real = 0, c1_pad = 0, c2 = 0, ly = 0, off0 = 0, orow0 = 0;
     int cb_off = -1;    // offset into the 1792-wide cond/time bias rows, -1 = none
 };
@@ -422,11 +424,16 @@ constexpr int kWino1dMinRows = 384;       // launch sets of at least this many r
                                           // direct / Winograd: 38.7 / 48.0 ms at 256 rows, 60.1 / 51.8 at 384, 60.7 / 53.3 at 512, 89.5 / 70.8 at 768, 102.3 / 75.1 at
                                           // 1,024, 189.8 / 134.3 at 2,048; launches of fewer than 512 whole items run as half items, wino1d_kernels.hip; below 384
                                           // rows a launch is a few workgroups' serial MFMA chain and the direct form's small tiles spread it wider)
+// the rule itself, a function of the layer shape, the rows of the launch set and what a test forced (cld_debug_conv5_form exposes it)
+bool conv5_takes_winograd(int l_in, int c1, int c2, int c_out, long b_pad, int forced) {
+    if (!wino1d_supported(l_in, c1, c2, c_out) || forced == CLD_FORM_DIRECT) return false;
+    const long widest = c1 > c_out ? c1 : c_out;      // the Winograd kernel addresses its tensors with 32-bit byte offsets (per source tensor)
+    if (b_pad * l_in * widest * 4 >= (1L << 31)) return false;
+    return forced == CLD_FORM_WINOGRAD || b_pad >= kWino1dMinRows;
+}
 bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
-    if (!l.ufrag || h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_DIRECT) return false;
-    const long widest = l.c1_real > l.c_out ? l.c1_real : l.c_out;      // the Winograd kernel addresses its tensors with 32-bit byte offsets
-    if ((long)b_pad * l.g.l_in * widest * 4 >= (1L << 31)) return false;
-    return h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_WINOGRAD || b_pad >= kWino1dMinRows;
+    if (!l.ufrag || !l.wino_launch) return false;
+    return conv5_takes_winograd(l.g.l_in, l.c1_real, l.c2, l.c_out, b_pad, h->force_kernel[CLD_KERNEL_CONV5]);
 }
 // FLOP a conv launch stands for (2 x output rows x K x N over the real channels) and FLOP its MFMAs execute in the form
 // the launch takes: the direct form pads the 4-channel latent's K to (tap, channel) = 20; the Winograd form runs 8 GEMMs over
@@ -525,7 +532,7 @@ bool use_chains(cld_handle h, int b_pad) {
     if (h->precision != CLD_PRECISION_F32) return false;
     const int f = h->force_kernel[CLD_KERNEL_UNET];
     if (f == CLD_FORM_LAYERS) return false;
-    if (f == CLD_FORM_CHAIN || f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4) return true;
+    if (f == CLD_FORM_CHAIN || f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4 || f == CLD_FORM_CHAIN_WINO) return true;
     (void)b_pad;
     return true;              // measured faster than one launch per layer at every batch size (profiles/r03/chain_check.txt)
 }
@@ -534,8 +541,16 @@ bool use_chains(cld_handle h, int b_pad) {
 int chain_tile(cld_handle h, int b_pad) {
     const int f = h->force_kernel[CLD_KERNEL_UNET];
     if (f == CLD_FORM_CHAIN_TILE1) return 1;
-    if (f == CLD_FORM_CHAIN_TILE4) return 4;
+    if (f == CLD_FORM_CHAIN_TILE4 || f == CLD_FORM_CHAIN_WINO) return 4;
     return b_pad <= kChainSmall ? 1 : 4;
+}
+// the four-agent chain tiles run their 64 -> 64 k5 layers in Winograd F(4, 5) form (chain_wino.hip) unless a test forces the direct
+// form of the k5 layers (CLD_KERNEL_CONV5) or of the chains (CLD_FORM_CHAIN_TILE4)
+bool chain_wino(cld_handle h, int b_pad) {
+    const int f = h->force_kernel[CLD_KERNEL_UNET];
+    if (f == CLD_FORM_CHAIN_WINO) return true;
+    if (f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4) return false;
+    return chain_tile(h, b_pad) == 4 && h->force_kernel[CLD_KERNEL_CONV5] != CLD_FORM_DIRECT;
 }
 
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
@@ -570,7 +585,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ca.x = x;
         auto stage = [&](const ConvLayer& l, int res_kind, int keep) {
             ChainStage st{};
-            st.wfrag = l.wfrag; st.bias = l.bias; st.gamma = l.gamma; st.beta = l.beta; st.cb_off = l.cb_off;
+            st.wfrag = l.wfrag; st.ufrag = l.ufrag; st.bias = l.bias; st.gamma = l.gamma; st.beta = l.beta; st.cb_off = l.cb_off;
             st.res_kind = res_kind; st.keep = keep;
             return st;
         };
@@ -587,9 +602,10 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         ca.stamps = (h->stamp_buf && h->stamp_layer == 0) ? h->stamp_buf : nullptr;
         h->launch_counter += 5;
         h->eval_alg_flop += 2.0 * b_pad * 52.0 * 64 * (20 + 3 * 320) + 2.0 * b_pad * 26.0 * 64 * 192 + 2.0 * b_pad * 52.0 * 64 * 4;
-        h->eval_exec_flop += chain_head_exec_flop(b_pad, chain_tile(h, b_pad));
+        const bool cw = chain_wino(h, b_pad);
+        h->eval_exec_flop += cw ? chain_head_wino_exec_flop(b_pad) : chain_head_exec_flop(b_pad, chain_tile(h, b_pad));
         h->eval_launches++;
-        e = launch_chain_head(ca, b_pad, chain_tile(h, b_pad), s);
+        e = cw ? launch_chain_head_wino(ca, b_pad, s) : launch_chain_head(ca, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
     } else {
     {   // block 0: conv(4 -> 64) | conv(64 -> 64) + residual_conv(x), the 1x1 projection of the latent evaluated in the epilogue
@@ -625,7 +641,7 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         if (e != hipSuccess) return e;
         auto stage = [&](const ConvLayer& l, int res_kind, int keep, const float* res) {
             ChainStage st{};
-            st.wfrag = l.wfrag; st.bias = l.bias; st.gamma = l.gamma; st.beta = l.beta; st.cb_off = l.cb_off;
+            st.wfrag = l.wfrag; st.ufrag = l.ufrag; st.bias = l.bias; st.gamma = l.gamma; st.beta = l.beta; st.cb_off = l.cb_off;
             st.res_kind = res_kind; st.keep = keep; st.res = res;
             return st;
         };
@@ -649,9 +665,10 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         }
         h->launch_counter += 6;
         h->eval_alg_flop += 2.0 * b_pad * 26.0 * 64 * (3 * 320) + 2.0 * b_pad * 52.0 * 64 * 128 + 2.0 * b_pad * 52.0 * 64 * 320 + 2.0 * b_pad * 52.0 * 4 * 64;
-        h->eval_exec_flop += chain_tail_exec_flop(b_pad, chain_tile(h, b_pad));
+        const bool cw = chain_wino(h, b_pad);
+        h->eval_exec_flop += cw ? chain_tail_wino_exec_flop(b_pad) : chain_tail_exec_flop(b_pad, chain_tile(h, b_pad));
         h->eval_launches++;
-        e = launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
+        e = cw ? launch_chain_tail_wino(ct, b_pad, s) : launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
         h->eps_in_buf7 = true;
     } else {
@@ -753,9 +770,14 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 4 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 5 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
+}
+
+int cld_debug_conv5_form(int32_t l_in, int32_t c1, int32_t c2, int32_t c_out, int64_t rows, int32_t forced_form) {
+    if (l_in < 1 || c1 < 1 || c2 < 0 || c_out < 1 || rows < 0 || forced_form < 0 || forced_form > 2) return CLD_ERR_ARG;
+    return conv5_takes_winograd(l_in, c1, c2, c_out, (long)((rows + 15) / 16 * 16), forced_form) ? CLD_FORM_WINOGRAD : CLD_FORM_DIRECT;
 }
 
 int cld_profile_enable(cld_handle h, int32_t on) {
@@ -867,7 +889,9 @@ int cld_finalize(cld_handle h, void* stream) {
                                     : ain       ? pack_conv_weights_split(wget, c_out, c1_pad + c2, ntaps)
                                                 : pack_conv_weights(wget, c_out, c1_pad + c2, ntaps);
         UP(l.wfrag, packed);
-        if (!split && !transposed && stride == 1 && ntaps == 5 && epi == EPI_GN_MISH && wino1d_supported(L_in, c1_real, c2, c_out)) {
+        const bool chain_k5 = (L_in == 52 || L_in == 26) && c1_real == 64 && c2 == 0 && c_out == 64;
+        l.wino_launch = wino1d_supported(L_in, c1_real, c2, c_out);
+        if (!split && !transposed && stride == 1 && ntaps == 5 && epi == EPI_GN_MISH && (l.wino_launch || chain_k5)) {
             // F(4, 5) at the points {0, +-1, +-2, +-1/2, inf}: U[xi][ci][co] = sum_k G[xi][k] w[co][ci][k], in double
             static const double Gm[8][5] = {{-1, 0, 0, 0, 0},
                                             {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},

@@ -87,6 +87,7 @@ enum { CHAIN_RES_NONE = 0, CHAIN_RES_LATENT = 1 /* residual_conv(latent), evalua
        CHAIN_RES_KEPT = 2 /* the block input kept by an earlier stage */, CHAIN_RES_TENSOR = 3 /* [b_pad, L, 64] in HBM */ };
 struct ChainStage {
     const float* wfrag;   // pack_conv_weights layout (pack_latent_conv_weights for the latent's conv)
+    const float* ufrag;   // k5 layers: the Winograd-domain filters G g (pack_conv_weights layout, the 8 transform points as taps), or null
     const float* bias;    // [64]
     const float* gamma;   // GroupNorm weight / bias (null for bias-only stages)
     const float* beta;
@@ -132,6 +133,11 @@ struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_c
     unsigned long long seed, step_salt;
 };
 hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile /* 4 | 1 */, hipStream_t s);
+// the same two launches with their 64 -> 64 k5 layers in Winograd F(4, 5) form (chain_wino.hip; four-agent tiles; every k5 stage needs ufrag)
+hipError_t launch_chain_head_wino(const ChainHeadArgs& a, int b_pad, hipStream_t s);
+hipError_t launch_chain_tail_wino(const ChainTailArgs& a, int b_pad, hipStream_t s);
+double chain_head_wino_exec_flop(int b_pad);
+double chain_tail_wino_exec_flop(int b_pad);
 // FLOP the MFMAs of a chain launch execute (2,048 per v_mfma_f32_16x16x4_f32, padded M-tiles and N columns included)
 double chain_head_exec_flop(int b_pad, int agents_per_tile);
 double chain_tail_exec_flop(int b_pad, int agents_per_tile);

@@ -411,6 +411,13 @@ int cld_guidance_losses(cld_handle h, const float* traj, const cld_guidance* gui
 int cld_world_step(cld_handle h, const float* traj, const float* centroid, const float* yaw, int32_t k, float* world,
                    float* next_curr_states, int32_t B, void* stream);
 
+/* Which form a Conv1d(k5) + GroupNorm + Mish launch takes (no handle, no device call; tests): CLD_FORM_WINOGRAD or CLD_FORM_DIRECT for a
+ * layer with `c1` (+ `c2` concatenated) input channels, `c_out` output channels and `l_in` rows per agent in a launch set of `rows` agents
+ * (padded to 16 inside), with `forced_form` = what cld_debug_force_kernel(CLD_KERNEL_CONV5, ...) would hold (CLD_FORM_AUTO: by size).
+ * The Winograd kernels address their tensors with 32-bit byte offsets: a launch whose widest tensor reaches 2 GiB falls back to the
+ * direct form whatever is forced.  Layers without a Winograd instance always answer CLD_FORM_DIRECT.  < 0: bad argument. */
+int cld_debug_conv5_form(int32_t l_in, int32_t c1, int32_t c2, int32_t c_out, int64_t rows, int32_t forced_form);
+
 /* Measurement aid for bench.py (no reference counterpart): while enabled, every launch of the
  * dominant kernel instance -- the Conv1d(k=5) + GroupNorm + Mish block producing 256 channels at
  * L = 13 (conv_block_kernel<13,13,1,5,32,*,*,1,32,1,0,0,0>: 7 launches per U-Net evaluation, all with 256 input
@@ -460,7 +467,9 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_FORM_LAYERS 1     /* CLD_KERNEL_UNET only */
 #define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only: chains, tile (4 agents | 1 agent per workgroup) by batch size */
 #define CLD_FORM_CHAIN_TILE1 3   /* CLD_KERNEL_UNET only: chains with one-agent tiles  */
-#define CLD_FORM_CHAIN_TILE4 4   /* CLD_KERNEL_UNET only: chains with four-agent tiles */
+#define CLD_FORM_CHAIN_TILE4 4   /* CLD_KERNEL_UNET only: chains with four-agent tiles, every layer in the direct form (conv_chain.hip) */
+#define CLD_FORM_CHAIN_WINO 5    /* CLD_KERNEL_UNET only: chains with four-agent tiles, their 64 -> 64 k5 layers in Winograd F(4, 5) form
+                                  * (chain_wino.hip; what CLD_FORM_AUTO / CLD_FORM_CHAIN take above 944 rows per launch set) */
 #define CLD_FORM_DIRECT 1     /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 #define CLD_FORM_WINOGRAD 2   /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);

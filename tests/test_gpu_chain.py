@@ -1,6 +1,7 @@
-"""GPU parity of the layer chains (csrc/conv_chain.hip): the 64-channel levels of a U-Net evaluation as two launches whose tiles
-stay in LDS from layer to layer (exact-fp32 handles; the default at every batch size: one-agent tiles up to 944 rows per launch
-set, four-agent tiles above).  Same bars as
+"""GPU parity of the layer chains (csrc/conv_chain.hip, csrc/chain_wino.hip): the 64-channel levels of a U-Net evaluation as two launches
+whose tiles stay in LDS from layer to layer (exact-fp32 handles; the default at every batch size: one-agent tiles in the direct form up to
+944 rows per launch set, four-agent tiles with the 64 -> 64 k5 layers in Winograd F(4, 5) form above).  Every golden case runs in both:
+"chain" (at the fixtures' small batches: one-agent direct tiles) and "chainw" (the Winograd four-agent tiles forced).  Same bars as
 tests/test_gpu_parity.py: every case is run with the chains forced on at sizes the golden fixtures and the oracle cover, and the
 automatic choice is checked at a launch size that takes it.
 """
@@ -28,15 +29,19 @@ def _engine(n=100, jitter=True, form="chain"):
     return e
 
 
-@pytest.fixture(scope="module")
-def eng():
-    return _engine()
+FORMS = ["chain", "chainw"]
 
 
+@pytest.fixture(scope="module", params=FORMS)
+def eng(request):
+    return _engine(form=request.param)
+
+
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("tag", ["default", "jitter"])
-def test_chains_unet_forward_golden(golden, tag):
+def test_chains_unet_forward_golden(golden, tag, form):
     meta, g = golden(f"unet_forward_{tag}")
-    e = _engine(100, meta["affine_jitter"])
+    e = _engine(100, meta["affine_jitter"], form)
     B = meta["B"]
     x = torch.from_numpy(synth.normal(meta["in_seed"], "unet_x", (B, 52, 4))) * 3.0
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
@@ -74,10 +79,11 @@ def test_chains_ddpm_step_golden(golden, eng):
         assert np.abs(xn.cpu().numpy() - g[f"x_next_t{i}"]).max() <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n,jitter", [(10, True), (50, True), (100, True)])
-def test_chains_full_chain_golden(golden, n, jitter):
+def test_chains_full_chain_golden(golden, n, jitter, form):
     meta, g = golden(f"sample_n{n}_{'jitter' if jitter else 'default'}")
-    e = _engine(n, jitter)
+    e = _engine(n, jitter, form)
     B = meta["B"]
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
     nz = synth.make_noise(B, n, meta["noise_seed"])
@@ -90,7 +96,8 @@ def test_chains_full_chain_golden(golden, n, jitter):
     assert np.allclose(logp.cpu().numpy(), g["log_prob_final"], atol=1e-4)
 
 
-def test_chains_small_chain_absolute_bar(golden):
+@pytest.mark.parametrize("form", FORMS)
+def test_chains_small_chain_absolute_bar(golden, form):
     """north_star's literal bar (<= 1e-3 ABSOLUTE per latent element over 100 steps) with the chains on."""
     from cld_amd.engine import Engine
     from tests.test_oracle_golden import small_chain_inputs
@@ -99,19 +106,22 @@ def test_chains_small_chain_absolute_bar(golden):
     e = Engine(n_timesteps=meta["n_timesteps"], device="cuda:0")
     e.load_state_dict(w)
     e.finalize()
-    e.force_kernel("unet", "chain")
+    e.force_kernel("unet", form)
     cond = torch.from_numpy(synth.make_inputs(meta["B"], meta["in_seed"])["cond_feat"])
     x0, x1, logp = e.sample(x_T, cond, noise=noise)
     for got, k in ((x0, "pred_traj"), (x1, "x1")):
-        assert float(np.abs(got.cpu().numpy() - g[k]).max()) <= 1e-3
+        err = float(np.abs(got.cpu().numpy() - g[k]).max())
+        print(f"chains ({form}): absolute-bar chain {k}: max|d| = {err:.3e}")
+        assert err <= 1e-3
     assert np.allclose(logp.cpu().numpy(), g["log_prob_final"], atol=1e-4)
 
 
-def test_chains_cfg_golden(golden):
+@pytest.mark.parametrize("form", FORMS)
+def test_chains_cfg_golden(golden, form):
     """CFG: the head combines the two halves of the chain's noise prediction [2B,52,4]."""
     meta, g = golden("sample_cfg_n10")
     B, n = meta["B"], meta["n_timesteps"]
-    e = _engine(n, True)
+    e = _engine(n, True, form)
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
     non_cond = torch.from_numpy(synth.normal(meta["in_seed"], "non_cond_feat", (B, 256)))
     nz = synth.make_noise(B, n, meta["noise_seed"])
@@ -141,11 +151,15 @@ def test_chains_are_the_default_and_agree_with_the_layer_launches(B):
     assert not torch.equal(auto, layers)             # two different kernels ran (their GroupNorm sums associate differently)
     assert float((auto - layers).abs().max()) <= 1e-5
     tiles = {}
-    for form in ("chain1", "chain4"):                # one- and four-agent tiles of the same chains (the batch size picks one)
+    for form in ("chain1", "chain4", "chainw"):      # one- and four-agent direct tiles, four-agent Winograd tiles (the batch size picks one)
         e.force_kernel("unet", form)
         tiles[form] = e.unet_forward(x, cond, 41).clone()
-    assert torch.equal(auto, tiles["chain1" if B <= 944 else "chain4"])
+    assert torch.equal(auto, tiles["chain1" if B <= 944 else "chainw"])
     assert float((tiles["chain1"] - tiles["chain4"]).abs().max()) <= 1e-5
+    assert not torch.equal(tiles["chainw"], tiles["chain4"])
+    dw = float((tiles["chainw"] - tiles["chain4"]).abs().max())
+    print(f"Winograd chain vs direct chain at {B} rows: max|d eps| = {dw:.3e}")
+    assert dw <= 1e-5
     rows = torch.tensor([0, 3, 4, B // 2 + 1, B - 2, B - 1])      # first / last tiles of the launch, both sides of a tile boundary
     ref = O.unet_forward(O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), x[rows], cond[rows],
                          torch.full((len(rows),), 41, dtype=torch.long))

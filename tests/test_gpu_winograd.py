@@ -122,7 +122,7 @@ def test_winograd_cfg_golden(golden):
         assert float(np.abs(got.cpu().numpy() - g[k]).max()) <= 1e-3 * scale
 
 
-@pytest.mark.parametrize("B", [300, 600, 1024, 2100])
+@pytest.mark.parametrize("B", [300, 600, 1024, 2100, 3200, 4096])
 def test_winograd_is_the_default_for_large_launch_sets_and_agrees_with_the_direct_form(B):
     from oracle import cld_oracle as O
     e = _engine(100, True, "auto")
@@ -134,7 +134,9 @@ def test_winograd_is_the_default_for_large_launch_sets_and_agrees_with_the_direc
     wino = e.unet_forward(x, cond, 41).clone()
     e.force_kernel("conv5", "direct")
     direct = e.unet_forward(x, cond, 41).clone()
-    assert torch.equal(auto, wino if B >= 384 else direct)           # (rows are padded to 16; launches of fewer than 512 whole items run as half items)
+    # (rows are padded to 16; launches of fewer than 512 whole items run as half items: up to 2,100 rows every instance does; at 3,200 rows
+    # the 256-channel launches run 800 whole items -- a full generation of 512 and a partly filled one --, at 4,096 rows 1,024 = two full ones)
+    assert torch.equal(auto, wino if B >= 384 else direct)
     assert not torch.equal(wino, direct)             # two different kernels ran
     assert float((wino - direct).abs().max()) <= 1e-5
     rows = torch.tensor([0, 3, 15, 16, B // 2 + 1, B - 2, B - 1])      # first / last workgroups, both sides of a 16-agent boundary

@@ -207,10 +207,35 @@ def test_force_kernel_tables_match_header():
     for name, macro in kernels.items():
         assert _lib.KERNELS[name] == defs["CLD_KERNEL_" + macro], name
     forms = {"auto": "AUTO", "valu": "VALU", "mfma": "MFMA", "quad": "MFMA_QUAD", "layers": "LAYERS", "chain": "CHAIN", "chain1": "CHAIN_TILE1",
-             "chain4": "CHAIN_TILE4", "direct": "DIRECT", "winograd": "WINOGRAD"}
+             "chain4": "CHAIN_TILE4", "chainw": "CHAIN_WINO", "direct": "DIRECT", "winograd": "WINOGRAD"}
     assert set(_lib.FORMS) == set(forms)
     for name, macro in forms.items():
         assert _lib.FORMS[name] == defs["CLD_FORM_" + macro], name
+
+
+def test_conv5_form_rule_and_its_32_bit_fallback():
+    """Which form a k5 launch takes is a pure rule of the library (cld_debug_conv5_form; csrc/cld_api.hip conv5_takes_winograd): Winograd
+    F(4, 5) from 384 rows per launch set for the layer shapes that have an instance, the direct form below, for other shapes, when forced
+    -- and whenever the launch's widest tensor reaches 2 GiB, because the Winograd kernels address their tensors with 32-bit byte
+    offsets (the direct kernels use 64-bit row bases): forcing Winograd does not override that."""
+    from cld_amd import _lib
+    f = _lib.load().cld_debug_conv5_form
+    AUTO, DIRECT, WINO = _lib.FORMS["auto"], _lib.FORMS["direct"], _lib.FORMS["winograd"]
+    shapes = [(13, 256, 0, 256), (13, 128, 0, 128), (13, 128, 0, 256), (13, 256, 256, 128), (26, 128, 0, 128), (26, 64, 0, 128), (26, 128, 128, 64)]
+    for (l, c1, c2, co) in shapes:
+        assert f(l, c1, c2, co, 383 // 16 * 16, AUTO) == DIRECT and f(l, c1, c2, co, 384, AUTO) == WINO      # the size threshold
+        assert f(l, c1, c2, co, 369, AUTO) == WINO                                                           # 369 rows pad to 384
+        assert f(l, c1, c2, co, 16, WINO) == WINO and f(l, c1, c2, co, 1 << 16, DIRECT) == DIRECT           # forcing
+        widest = max(c1, co)
+        edge = (1 << 31) // (l * widest * 4)                 # rows at which the widest tensor reaches 2 GiB
+        below = edge // 16 * 16
+        if below * l * widest * 4 >= 1 << 31:
+            below -= 16
+        assert f(l, c1, c2, co, below, AUTO) == WINO and f(l, c1, c2, co, below, WINO) == WINO
+        assert f(l, c1, c2, co, below + 16, AUTO) == DIRECT and f(l, c1, c2, co, below + 16, WINO) == DIRECT, (l, c1, c2, co)
+    for (l, c1, c2, co) in [(52, 64, 0, 64), (26, 64, 0, 64), (13, 256, 0, 128), (52, 4, 0, 64), (26, 128, 0, 256)]:      # no launch of its own in Winograd form
+        assert f(l, c1, c2, co, 4096, AUTO) == DIRECT and f(l, c1, c2, co, 4096, WINO) == DIRECT
+    assert f(13, 256, 0, 256, -1, AUTO) < 0 and f(13, 256, 0, 256, 64, 3) < 0
 
 
 def test_timers_keep_the_reference_surface():
