@@ -262,6 +262,7 @@ def main():
         roof = None
         if profile:
             ms, launches, flop = eng.profile_read()
+            ex_flop = eng.profile_read_executed()[0]      # (before profile_enable resets the counters)
             eng.profile_enable(False)
             rows = (B + 15) // 16 * 16 * (2 if wl["cfg_w"] else 1)      # agents per conv launch (CFG batches both passes)
             if launches > 0 and ms > 0:
@@ -276,7 +277,6 @@ def main():
                 # cld_profile_read_executed) / time / peak -- a utilisation, <= 1 by construction.  The Winograd F(4, 5) form computes the
                 # same sums with 8 x 4 MFMA k-steps per agent and channel pair instead of 5 x 13, so the rate counted on the direct
                 # form's multiplies (SURVEY 8d's unit) can pass the pipe's peak: it is reported under its own name, never as `frac`.
-                ex_flop = eng.profile_read_executed()[0]
                 ex_ach = ex_flop / (ms * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": round(ex_ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(ex_ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],

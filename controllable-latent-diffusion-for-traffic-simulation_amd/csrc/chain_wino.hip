@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
     Rows<W> rw;
     rw.init(i16);
     float* gnw = gn + wave * 256;
+    CSTAMP(0);
+    CSTAMP_RT(14);
 
     // V addressing: rows of 64 channels = 16 slots of 16 bytes, slot s of row r at s ^ (r & 15): the four 16-lane groups of a ds_read_b128
     // then touch every bank once.  Fragment of chunk c: slot 4 c + kk; this lane's own channels: slot 4 wave + kk.
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
         }
         gn_mish_rows<W>(Y, rw, *reinterpret_cast<const v4f*>(st.gamma + n4), *reinterpret_cast<const v4f*>(st.beta + n4), add, gnw, i16, kk);
     }
+    CSTAMP(1);
 
     // ---- stages 1..3: Conv1d(64 -> 64, k5) + GroupNorm + Mish [+ vectors] [+ residual] in Winograd form; one code instance ----
     v4f* keep = reinterpret_cast<v4f*>(p.keep) + (size_t)blockIdx.x * (NM * 4) * 256 + tid;
@@ -395,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
         const ChainStage& st = p.st[s];
         v4f acc[8][NM];
         wino_layer<W>(Y, acc, rw, ldsb, aoff, wofs, i16, uq, st.ufrag, wvoff, wsoff);
+        CSTAMP(2 * s);
         out_transform<NM>(acc, *reinterpret_cast<const v4f*>(st.bias + n4), Y);
         // the next layer's first weight fragments travel under this layer's epilogue
         if (s < 3) uprime<W, 0>(uq, p.st[s + 1].ufrag, wvoff, wsoff);
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
 #pragma unroll
             for (int m = 0; m < NM; ++m)
 #pragma unroll
-                for (int o = 0; o < 4; ++o) Y[m][o] += keep[(m * 4 + o) * 256];
+                for (int o = 0; o < 4; ++o) Y[m][o] += keep[(m * 4 + o) * 256];      // (written by this workgroup two layers ago: an L2 hit)
         }
         if (st.keep) {
 #pragma unroll
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
 #pragma unroll
                 for (int o = 0; o < 4; ++o) keep[(m * 4 + o) * 256] = Y[m][o];
         }
+        CSTAMP(2 * s + 1);
     }
 
     // ---- stage 4: Conv1d(64 -> 64, k3, stride 2, pad 1) + bias -> [B,26,64], from the spatial image (conv_chain.hip) ----
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
 #pragma unroll
         for (int m = 0; m < GO::NMT; ++m) acd[m] = v4f{0.f, 0.f, 0.f, 0.f};
         kloop<G::KCP, 2 * MSTEP, 64, 3, GO::NMT>(acd, ldsb, ((n16 % 4) * G::ASTR + (1 + 2 * (n16 / 4)) * G::KCP + 4 * q) * 4, rsw, lane * 16, 4, wave, wqd);
+        CSTAMP(8);
         const float bias = st.bias[n];
         const size_t ybase = (size_t)b0 * 26 * 64;
         const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y + ybase, 0, 4 * 26 * 64 * 4, 0x00020000);
@@ -459,6 +465,8 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acd[m][r] + bias), rsy,
                                                           ((GO::agent(q, r) * 26 + GO::pos(m, q, r)) * 64 + n) * 4, 0, CLD_STORE_AUX);
     }
+    CSTAMP(9);
+    CSTAMP_RT(15);
 }
 
 constexpr size_t kHeadWinoLds = sizeof(float) * (kVFloats + kGnFloats + 4 * 56 * 4);
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
                 add[m] = tb;
                 if (st.cb_off >= 0) add[m] += *reinterpret_cast<const v4f*>(p.cbias + (size_t)(b0 + rw.al[m]) * p.cb_stride + st.cb_off + n4);
             }
-            gn_mish_rows<W>(Y, rw, *reinterpret_cast<const v4f*>(st.gamma + n4), *reinterpret_cast<const v4f*>(st.beta + n4), add, gnw, i16, kk);
+            v4f rres[W::NM][4];                          // residual rows, requested ahead of the GroupNorm passes that cover their latency
             if (st.res_kind == CHAIN_RES_TENSOR) {
                 const int rbytes = 4 * 26 * 64 * 4;      // rows past the agent's end: out of range, read 0
                 const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.res + (size_t)b0 * 26 * 64), 0, rbytes, 0x00020000);
@@ -549,13 +557,20 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         const int pos = 4 * rw.tl[m] + o;
-                        Y[m][o] += bload16(rsr, (rw.lv[m] && pos < 26) ? ((rw.al[m] * 26 + pos) * 64 + n4) * 4 : rbytes, 0);
+                        rres[m][o] = bload16(rsr, (rw.lv[m] && pos < 26) ? ((rw.al[m] * 26 + pos) * 64 + n4) * 4 : rbytes, 0);
                     }
             } else if (st.res_kind == CHAIN_RES_KEPT) {
 #pragma unroll
                 for (int m = 0; m < W::NM; ++m)
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) Y[m][o] += keep[(m * 4 + o) * 256];
+                    for (int o = 0; o < 4; ++o) rres[m][o] = keep[(m * 4 + o) * 256];
+            }
+            gn_mish_rows<W>(Y, rw, *reinterpret_cast<const v4f*>(st.gamma + n4), *reinterpret_cast<const v4f*>(st.beta + n4), add, gnw, i16, kk);
+            if (st.res_kind == CHAIN_RES_TENSOR || st.res_kind == CHAIN_RES_KEPT) {
+#pragma unroll
+                for (int m = 0; m < W::NM; ++m)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) Y[m][o] += rres[m][o];
             }
             if (st.keep) {
 #pragma unroll

@@ -213,6 +213,8 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
         return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff, item * (G::NTN * 1024) + wsoff, 0));
     };
 
+    const int n4 = cb * 64 + 16 * wave + 4 * kk;         // epilogue: this lane's four output channels
+    const v4f bias = *reinterpret_cast<const v4f*>(p.bias + n4);      // (requested here: the output transform would wait for it)
     v4f acc[8][NM];
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi)
@@ -267,8 +269,6 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
     W1STAMP(2);
 
     // ---- epilogue.  Lane: channels n4 .. n4 + 3; M-tile m: row 16 m + i16 = (agent row / TPA, tile t = row % TPA), outputs at 4 t + o ----
-    const int n4 = cb * 64 + 16 * wave + 4 * kk;
-    const v4f bias = *reinterpret_cast<const v4f*>(p.bias + n4);
     int al[NM], tl[NM];                                   // agent (within the workgroup) and tile of this lane's row of M-tile m
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -288,6 +288,37 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
         Y[m][2] = fma4(p56, 0.25f, fma4(p34, 4.0f, p12)) + bias;
         Y[m][3] = (fma4(m56, 0.125f, fma4(m34, 8.0f, m12)) + acc[7][m]) + bias;
     }
+    // Every operand of the second half of the epilogue is requested NOW, behind the output transform: residual rows, per-agent and
+    // per-step vectors, GroupNorm affine.  The two statistics passes below (two workgroup barriers in the 32-channel-group case) cover
+    // their latency; requested where they are used -- per M-tile, in front of their first use -- each M-tile of the epilogue waited out
+    // a trip to L2 / HBM with both workgroups of every CU doing the same at the same moment (5 exposed round trips per workgroup).
+    // Output and residual go through buffer descriptors: one 32-bit offset per (M-tile, lane), the four outputs of a tile at immediate
+    // distances, a dead output (past the end of the agent, an idle row) at an out-of-range offset -- dropped by the range check: no
+    // 64-bit address arithmetic and no branch per store
+    __builtin_amdgcn_sched_barrier(0);                    // (not before the accumulators are dead: 128 + 92 registers would not fit)
+    const int ybytes = b_pad * L * COUT * 4;
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, ybytes, 0x00020000);
+    const bool has_res = p.res != nullptr;
+    int ooff[NM][4];
+    v4f rv[NM][4], cbv[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        const int b = b0 + al[m];
+        const bool rowok = ROWS == 16 * NM || 16 * m + i16 < ROWS;
+        const int obase = (((b * L + 4 * tl[m]) * COUT) + n4) * 4;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) ooff[m][o] = (rowok && 4 * tl[m] + o < L) ? obase + o * (COUT * 4) : ybytes;
+        if (has_res) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) rv[m][o] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsr, ooff[m][o], 0, 0));
+        }
+        cbv[m] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (p.cbias && rowok) cbv[m] = *reinterpret_cast<const v4f*>(p.cbias + (size_t)b * p.cb_stride + n4);
+    }
+    const v4f gam = *reinterpret_cast<const v4f*>(p.gamma + n4), bet = *reinterpret_cast<const v4f*>(p.beta + n4);
+    const v4f tb = p.tbias ? *reinterpret_cast<const v4f*>(p.tbias + n4) : v4f{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
     // GroupNorm(GS channels x L rows per agent, eps 1e-5, biased variance, two passes; diffuser_helpers.py:61).  group_totals() turns a
     // lane's partial sums (its 4 channels x its row's outputs) into the group's totals:
     //   L = 13: an agent's four tiles are a quad of lanes -> DPP + permlane sums; a 32-channel group's other half lives in wave w ^ 1;
@@ -361,37 +392,16 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
     }
     group_totals(s2, xch + G::XCH / 2);
     W1STAMP(3);
-    const v4f gam = *reinterpret_cast<const v4f*>(p.gamma + n4), bet = *reinterpret_cast<const v4f*>(p.beta + n4);
-    const v4f tb = p.tbias ? *reinterpret_cast<const v4f*>(p.tbias + n4) : v4f{0.f, 0.f, 0.f, 0.f};
-    // output and residual through buffer descriptors: one 32-bit offset per (M-tile, lane), the four outputs of a tile at immediate
-    // distances, a dead output (past the end of the agent, an idle row) at an out-of-range offset -- dropped by the range check: no
-    // 64-bit address arithmetic and no branch per store
-    const int ybytes = b_pad * L * COUT * 4;
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, ybytes, 0x00020000);
-    const bool has_res = p.res != nullptr;
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        const int b = b0 + al[m];
-        const bool rowok = ROWS == 16 * NM || 16 * m + i16 < ROWS;
-        const int obase = (((b * L + 4 * tl[m]) * COUT) + n4) * 4;
-        int ooff[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) ooff[o] = (rowok && 4 * tl[m] + o < L) ? obase + o * (COUT * 4) : ybytes;
-        v4f rv[4];
-        if (has_res) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o) rv[o] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsr, ooff[o], 0, 0));
-        }
         const v4f sc = (1.0f / sqrtf(s2[m] * inv + 1e-5f)) * gam;
-        v4f add = tb;
-        if (p.cbias && rowok) add += *reinterpret_cast<const v4f*>(p.cbias + (size_t)b * p.cb_stride + n4);
+        const v4f add = tb + cbv[m];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             const v4f x = __builtin_elementwise_fma(Y[m][o] - mean[m], sc, bet);
             v4f v = mish4(x) + add;
-            if (has_res) v += rv[o];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rsy, ooff[o], 0, 0);
+            if (has_res) v += rv[m][o];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rsy, ooff[m][o], 0, 0);
         }
     }
     W1STAMP(4);
