@@ -56,7 +56,7 @@ class CldCollision(C.Structure):
     _fields_ = [("extent", C.c_void_p), ("world_from_agent", C.c_void_p), ("curr_speed", C.c_void_p),
                 ("scene_start", C.c_void_p), ("scene_weight", C.c_void_p), ("guided", C.c_void_p),
                 ("num_scenes", C.c_int32), ("num_samp", C.c_int32), ("num_disks", C.c_int32), ("max_scene_agents", C.c_int32),
-                ("buffer_dist", C.c_float), ("decay_rate", C.c_float), ("moving_speed_th", C.c_float)]
+                ("buffer_dist", C.c_float), ("decay_rate", C.c_float), ("moving_speed_th", C.c_float), ("excluded", C.c_void_p)]
 
 
 class CldMapCollision(C.Structure):

@@ -474,12 +474,8 @@ static_assert(sizeof(float) * img_floats<4>() <= sizeof(float) * (kVFloats + kGn
 static_assert(2 * kHeadWinoLds <= 160 * 1024, "two workgroups per CU");
 
 hipError_t launch_chain_head_wino(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_head_wino_kernel), 160 * 1024, &attr_done); e != hipSuccess) return e;
     if (b_pad % 4) return hipErrorInvalidValue;
     for (int i = 1; i <= 3; ++i)
         if (!a.st[i].ufrag) return hipErrorInvalidValue;
@@ -704,12 +700,8 @@ constexpr size_t kTailWinoLds = sizeof(float) * (kVFloats + kGnFloats);
 static_assert(sizeof(float) * img_floats<4>() <= kTailWinoLds, "the spatial images fit in the V region");
 
 hipError_t launch_chain_tail_wino(const ChainTailArgs& a, int b_pad, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_tail_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_tail_wino_kernel), 160 * 1024, &attr_done); e != hipSuccess) return e;
     if (b_pad % 4 || !a.st[0].ufrag || !a.st[1].ufrag || !a.st[2].ufrag || !a.fin.ufrag) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chain_tail_wino_kernel, dim3(b_pad / 4), dim3(256), kTailWinoLds, s, a);
     return hipGetLastError();

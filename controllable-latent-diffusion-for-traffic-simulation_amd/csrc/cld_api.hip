@@ -1425,10 +1425,10 @@ static int run_guidance(cld_handle h, const Ws& w, const cld_guidance* gd, int B
             const cld_collision* c = gd->collision;
             CollisionArgs ca{};
             ca.traj = w.col_traj; ca.extent = c->extent; ca.world_from_agent = c->world_from_agent; ca.curr_speed = c->curr_speed;
-            ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.grad_in = gd->ext_grad;
+            ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.excluded = c->excluded; ca.max_scene_agents = c->max_scene_agents; ca.grad_in = gd->ext_grad;
             ca.grad = w.col_grad; ca.B_agents = B / c->num_samp; ca.num_scenes = c->num_scenes; ca.num_samp = c->num_samp;
             ca.num_disks = c->num_disks; ca.buffer_dist = c->buffer_dist; ca.decay_rate = c->decay_rate; ca.moving_speed_th = c->moving_speed_th;
-            HIPCK(h, launch_agent_collision(ca, c->max_scene_agents, s));
+            HIPCK(h, launch_agent_collision(ca, s));
             g.ext_grad = w.col_grad;
         }
         if (gd->map_collision) {                     // adds to whatever gradient is there already (caller's ext_grad, agent collisions)
@@ -1795,10 +1795,10 @@ int cld_agent_collision(cld_handle h, const float* traj, const cld_collision* c,
     if (rc) return rc;
     CollisionArgs ca{};
     ca.traj = traj; ca.extent = c->extent; ca.world_from_agent = c->world_from_agent; ca.curr_speed = c->curr_speed;
-    ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.grad_in = grad_in;
+    ca.scene_start = c->scene_start; ca.scene_weight = c->scene_weight; ca.guided = c->guided; ca.excluded = c->excluded; ca.max_scene_agents = c->max_scene_agents; ca.grad_in = grad_in;
     ca.loss = loss; ca.grad = grad; ca.B_agents = B / c->num_samp; ca.num_scenes = c->num_scenes; ca.num_samp = c->num_samp;
     ca.num_disks = c->num_disks; ca.buffer_dist = c->buffer_dist; ca.decay_rate = c->decay_rate; ca.moving_speed_th = c->moving_speed_th;
-    HIPCK(h, launch_agent_collision(ca, c->max_scene_agents, static_cast<hipStream_t>(stream)));
+    HIPCK(h, launch_agent_collision(ca, static_cast<hipStream_t>(stream)));
     return CLD_OK;
 }
 

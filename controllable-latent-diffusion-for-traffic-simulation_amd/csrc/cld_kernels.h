@@ -5,6 +5,19 @@
 
 namespace cld {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel AND device: `done_mask` is the launcher's static, one bit per device
+// ordinal (a process-wide flag left the attribute unset on a second device)
+inline hipError_t set_max_lds_once(const void* fn, int bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((*done_mask >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) *done_mask |= 1ull << dev;
+    return hipSuccess;
+}
+
 // ---------------------------------------------------------------------------
 // Activation layout in HBM: channels-last [B_pad, L, C] fp32, B_pad = B rounded
 // up to 16 agents.  All three U-Net resolutions hold 3,328 floats per agent at
@@ -319,13 +332,16 @@ struct CollisionArgs {
     const int* scene_start;         // [num_scenes + 1] agent offsets of the scenes
     const float* scene_weight;      // [num_scenes] weight of the scene's agent_collision config (0: not guided) or null (1 everywhere)
     const unsigned char* guided;    // [B_agents] or null: the config's `agents` subset
+    const unsigned char* excluded;  // [B_agents] or null: upstream's `excluded_agents` -- a pair whose agents are BOTH flagged is not penalised (:586-593)
     const float* grad_in;           // [B_agents * num_samp, 52, 6] or null: added to the output gradient
     float* loss;                    // [B_agents * num_samp] per-agent values (unweighted, as upstream files them) or null
     float* grad;                    // [B_agents * num_samp, 52, 6] d total / d traj, or null
     int B_agents, num_scenes, num_samp, num_disks;
+    int max_scene_agents;           // what the launch sized its LDS and grid for: a scene with more agents (scene_start is device data the host
+                                    // cannot check) gets NaN values and a gradient of grad_in (or 0) instead of an overrun
     float buffer_dist, decay_rate, moving_speed_th;
 };
-hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, hipStream_t s);
+hipError_t launch_agent_collision(const CollisionArgs& a, hipStream_t s);
 
 // upstream's MapCollisionLoss + its gradient w.r.t. the decoded plans (collision_kernels.hip; guidance_loss.py:717-875)
 struct MapCollisionArgs {

@@ -38,8 +38,22 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
     const int s = blockIdx.x / p.num_samp, n = blockIdx.x % p.num_samp;
     const int a0 = p.scene_start[s], A = p.scene_start[s + 1] - a0;
     const int i0 = blockIdx.y * kOwn;                               // this workgroup's agents: i0 .. i0 + kOwn - 1 of the scene
-    if (i0 >= A) return;
     const int tid = threadIdx.x;
+    if (A > p.max_scene_agents) {
+        // the scene does not fit the launch (LDS and grid.y were sized from the host's max_scene_agents; scene_start is device data
+        // the host cannot check): no partial result -- every agent of the scene gets a NaN value and the gradient passed in (or 0)
+        if (blockIdx.y == 0)
+            for (int idx = tid; idx < A * TT; idx += 256) {
+                const int i = idx / TT, t = idx - i * TT;
+                if (t == 0 && p.loss) p.loss[(size_t)(a0 + i) * p.num_samp + n] = __builtin_nanf("");
+                if (p.grad) {
+                    const size_t o = ((size_t)((a0 + i) * p.num_samp + n) * TT + t) * 6;
+                    for (int k = 0; k < 6; ++k) p.grad[o + k] = p.grad_in ? p.grad_in[o + k] : 0.f;
+                }
+            }
+        return;
+    }
+    if (i0 >= A) return;
     float4* pose = reinterpret_cast<float4*>(lds);                 // [A][52]: world x, y, cos / sin of the world heading
     float* part = lds + (size_t)A * TT * 4;                        // [kOwn][52]: sum_j pen_ij(t) (weighted) of the own agents -> their values
     float* agent = part + (size_t)kOwn * TT;                       // [A][4]: radius, half extent of the disk centres, row-active flag, moving flag
@@ -57,7 +71,7 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
         agent[i * 4 + 0] = rad;
         agent[i * 4 + 1] = len * 0.5f - rad;                       // disk centres run from -this to +this along the agent's axis (:481-492)
         agent[i * 4 + 2] = (guided && moving) ? 1.f : 0.f;
-        agent[i * 4 + 3] = moving ? 1.f : 0.f;
+        agent[i * 4 + 3] = (moving ? 1.f : 0.f) + ((p.excluded && p.excluded[b]) ? 2.f : 0.f);      // bit 0: moving; bit 1: in `excluded_agents`
         if (guided) atomicAdd(&n_guided, 1);
     }
     // world poses (geometry_utils.py:458-483): p_w = R p + t; heading = atan2 of the rotated unit vector
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
         const int i = i0 + io / TT, t = io % TT, b = a0 + i, it = i * TT + t;
         const float4 pi = pose[it];
         const float ri = agent[i * 4 + 0], ei = agent[i * 4 + 1], acti = agent[i * 4 + 2];
+        const bool excl_i = ((int)agent[i * 4 + 3] & 2) != 0;
         const float wt = powf(p.decay_rate, (float)t) / wsum;
         float cxi[kMaxDisks];
 #pragma unroll
@@ -94,6 +109,7 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
         float pen_sum = 0.f, gx = 0.f, gy = 0.f, gyaw = 0.f;
         for (int j = 0; j < A; ++j) {
             if (j == i) continue;
+            if (excl_i && ((int)agent[j * 4 + 3] & 2)) continue;   // both in excluded_agents: the pair is not penalised (:586-593)
             const float4 pj = pose[j * TT + t];
             const float rj = agent[j * 4 + 0], ej = agent[j * 4 + 1];
             const float pd = ri + rj + p.buffer_dist;
@@ -146,22 +162,19 @@ __global__ __launch_bounds__(256) void agent_collision_kernel(const CollisionArg
             const int i = i0 + io;
             float v = 0.f;
             for (int t = 0; t < TT; ++t) v += part[io * TT + t];   // fixed order: deterministic
-            p.loss[(size_t)(a0 + i) * p.num_samp + n] = agent[i * 4 + 3] != 0.f ? v : 0.f;
+            p.loss[(size_t)(a0 + i) * p.num_samp + n] = ((int)agent[i * 4 + 3] & 1) ? v : 0.f;
         }
     }
 }
 }  // namespace
 
-hipError_t launch_agent_collision(const CollisionArgs& a, int max_scene_agents, hipStream_t s) {
-    if (a.num_disks < 1 || a.num_disks > kMaxDisks || a.num_scenes < 1 || a.num_samp < 1) return hipErrorInvalidValue;
+hipError_t launch_agent_collision(const CollisionArgs& a, hipStream_t s) {
+    const int max_scene_agents = a.max_scene_agents;
+    if (a.num_disks < 1 || a.num_disks > kMaxDisks || a.num_scenes < 1 || a.num_samp < 1 || max_scene_agents < 1) return hipErrorInvalidValue;
     const size_t lds_bytes = ((size_t)max_scene_agents * TT * 4 + (size_t)kOwn * TT + (size_t)max_scene_agents * 4 + 4) * sizeof(float);
     if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;          // a scene of more than ~190 agents: not built
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(agent_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(agent_collision_kernel), 160 * 1024, &attr_done); e != hipSuccess) return e;
     hipLaunchKernelGGL(agent_collision_kernel, dim3(a.num_scenes * a.num_samp, (max_scene_agents + kOwn - 1) / kOwn), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }

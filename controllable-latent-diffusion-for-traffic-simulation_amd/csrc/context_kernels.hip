@@ -467,13 +467,8 @@ template <int KH, int S, int HIN, int TR, int NA, int NB>
 static hipError_t launch_conv2d_inst(const Conv2dArgs& a, hipStream_t s) {
     typedef C2<KH, S, HIN, TR, NA, NB> G;
     auto kern = conv2d_kernel<KH, S, HIN, TR, NA, NB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
     const int groups = (a.B + NA - 1) / NA;
     dim3 grid(groups * (G::HO / TR), a.cout / 64, 1);
     hipLaunchKernelGGL(kern, grid, dim3(256), G::LDS_BYTES, s, a);

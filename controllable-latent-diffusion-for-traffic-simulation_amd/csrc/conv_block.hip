@@ -739,13 +739,8 @@ static hipError_t launch_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     constexpr size_t lds_bytes = sizeof(float) * ((size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE) + 64);   // + the GroupNorm exchange slots of the eighth-height tiles
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_block_kernel<L_IN, LM, STRIDE, NTAPS, KC, NWN, KS, EPI, GS, OSTR, PADC, AIN, AOUT, HM>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern), 160 * 1024, &attr_done); e != hipSuccess) return e;
     dim3 grid((b_pad / AG) * (a.c_out / (16 * NWN)), 1, 1);
     ConvArgs aa = a;
     aa.xcd_map = (int)grid.x > 256 * (NWN * KS == 8 ? 1 : 2);        // more workgroups than resident slots (tile_of_block)
@@ -761,13 +756,8 @@ static hipError_t launch_pair_inst(const ConvArgs& a, const ConvArgs& b, int b_p
     constexpr size_t lds_bytes = sizeof(float) * ((size_t)(2 * ABUF > OTILE ? 2 * ABUF : OTILE) + 64);
     static_assert(lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = conv_pair_kernel<L_IN, LM, KC, NWN, KS, GS, OSTR, PADC, NTAPS_A, EPI_A, NTAPS_B, EPI_B, AIN, AOUT, HM>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern), 160 * 1024, &attr_done); e != hipSuccess) return e;
     ConvPairArgs pa{a, b};
     dim3 grid((b_pad / AG) * (a.c_out / (16 * NWN)), 1, 2);
     pa.a.xcd_map = pa.b.xcd_map = 2 * (int)grid.x > 256 * (NWN * KS == 8 ? 1 : 2);

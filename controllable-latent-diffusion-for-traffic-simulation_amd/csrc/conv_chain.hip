@@ -169,12 +169,8 @@ template <int AG>
 static hipError_t launch_chain_head_inst(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
     constexpr size_t lds_bytes = sizeof(float) * (img_floats<AG>() + AG * 52 * 4);
     static_assert(2 * lds_bytes <= 160 * 1024, "two workgroups per CU");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_head_kernel<AG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_head_kernel<AG>), 160 * 1024, &attr_done); e != hipSuccess) return e;
     if (b_pad % AG) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chain_head_kernel<AG>, dim3(b_pad / AG), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
@@ -373,12 +369,8 @@ __global__ __launch_bounds__(256, 2) void chain_tail_kernel(const ChainTailArgs 
 template <int AG>
 static hipError_t launch_chain_tail_inst(const ChainTailArgs& a, int b_pad, hipStream_t s) {
     constexpr size_t lds_bytes = sizeof(float) * img_floats<AG>();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(chain_tail_kernel<AG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_tail_kernel<AG>), 160 * 1024, &attr_done); e != hipSuccess) return e;
     if (b_pad % AG) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chain_tail_kernel<AG>, dim3(b_pad / AG), dim3(256), lds_bytes, s, a);
     return hipGetLastError();

@@ -453,12 +453,8 @@ template <int L, int CIN, int CS, int COUT>
 static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     typedef W1Geo<L, CIN, CS, COUT> G;
     auto kern = wino1d_conv_kernel<L, CIN, CS, COUT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
     if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
     const int groups = b_pad / G::AG, nfull = groups * G::NCB;
     // whole items when they fill generations of 512 (two workgroups per CU); halves below one generation and when the last generation

@@ -297,13 +297,8 @@ __global__ __launch_bounds__(256, 2) void wino_conv_kernel(const WinoArgs p) {
 template <int HIN>
 static hipError_t launch_wino_inst(const WinoArgs& a, hipStream_t s) {
     typedef WinoGeo<HIN> G;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<HIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)G::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(wino_conv_kernel<HIN>), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
     const int groups = (a.B * G::TPA + G::MT - 1) / G::MT;
     hipLaunchKernelGGL(wino_conv_kernel<HIN>, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a);
     return hipGetLastError();

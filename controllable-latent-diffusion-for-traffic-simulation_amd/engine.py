@@ -158,6 +158,11 @@ class Engine:
                         "cld_unet_forward_t")
         return eps
 
+    #: Device-resident timesteps are CLAMPED to [0, n_timesteps) without a check, to keep the call asynchronous (host values always raise
+    #: when out of range).  Set True to have device tensors checked too -- a synchronising read per call; for debugging a caller that
+    #: draws timesteps itself (e.g. randint(0, n + 1) would otherwise be mapped to a valid step silently).  INTEGRATION.md, "Timesteps".
+    check_device_timesteps = False
+
     def _timesteps(self, t, B: int) -> torch.Tensor:
         """Per-row timesteps -> int32 [B] on the device.  Host values (lists, CPU tensors) are range-checked here; a device
         tensor is clamped to [0, n_timesteps) on the device instead, so the call stays asynchronous (the kernels index tables
@@ -169,6 +174,10 @@ class Engine:
             if t.numel() and (int(t.min()) < 0 or int(t.max()) >= self.n_timesteps):
                 raise CldError(f"timestep out of range [0, {self.n_timesteps})")
             return t.to(self.device, torch.int32).contiguous()
+        if self.check_device_timesteps:      # opt-in (Engine.check_device_timesteps = True): costs a device round trip per call
+            lo, hi = int(t.min()), int(t.max())
+            if lo < 0 or hi >= self.n_timesteps:
+                raise CldError(f"timestep out of range [0, {self.n_timesteps}): device tensor holds values in [{lo}, {hi}]")
         return t.to(self.device).clamp(0, self.n_timesteps - 1).to(torch.int32).contiguous()
 
     def q_sample(self, z0, noise, t):
@@ -274,7 +283,7 @@ class Engine:
     def _collision(self, c: Mapping, B: int):
         """dict(extent [A,3], world_from_agent [A,3,3], curr_speed [A], scene_index [A] (consecutive blocks) | scene_sizes,
         weight: scalar or per-scene sequence (0 = scene not guided), agents: optional {scene: local indices} (upstream's
-        `agents` of a guidance config), num_samp = 1, num_disks = 5, buffer_dist = 0.2, decay_rate = 0.9,
+        `agents` of a guidance config), excluded_agents: optional batch indices (upstream's `excluded_agents`), num_samp = 1, num_disks = 5, buffer_dist = 0.2, decay_rate = 0.9,
         guide_moving_speed_th = 0.5) -> (CldCollision, tensors kept alive): upstream's AgentCollisionLoss
         (src/tbsim/utils/guidance_loss.py:442-630) configured per scene as DiffuserGuidance does (:2106-2172).  B = A * num_samp."""
         N = int(c.get("num_samp", 1))
@@ -305,10 +314,19 @@ class Engine:
                 else:
                     gm[offs[s_] + np.asarray(sub, dtype=np.int64)] = 1
             guided = torch.from_numpy(gm).to(self.device)
+        excluded = None
+        if c.get("excluded_agents") is not None:        # upstream's `excluded_agents` (:447,586-593): batch indices; a pair of two flagged agents is not penalised
+            em = np.zeros(A, np.uint8)
+            idx = np.asarray(list(c["excluded_agents"]), dtype=np.int64).reshape(-1)
+            if idx.size and (idx.min() < 0 or idx.max() >= A):
+                raise CldError(f"agent_collision: excluded_agents out of range for {A} agents")
+            em[idx] = 1
+            excluded = torch.from_numpy(em).to(self.device)
         cc = _lib.CldCollision(ext.data_ptr(), wfa.data_ptr(), spd.data_ptr(), start.data_ptr(), wts.data_ptr(),
                                None if guided is None else guided.data_ptr(), S, N, int(c.get("num_disks", 5)), max(sizes),
-                               float(c.get("buffer_dist", 0.2)), float(c.get("decay_rate", 0.9)), float(c.get("guide_moving_speed_th", 0.5)))
-        return cc, (ext, wfa, spd, start, wts, guided)
+                               float(c.get("buffer_dist", 0.2)), float(c.get("decay_rate", 0.9)), float(c.get("guide_moving_speed_th", 0.5)),
+                               None if excluded is None else excluded.data_ptr())
+        return cc, (ext, wfa, spd, start, wts, guided, excluded)
 
     def _scene_blocks(self, c: Mapping, A: int, what: str):
         """-> (scene sizes, start offsets on the device, per-scene weights on the device) of a scene-structured loss config."""

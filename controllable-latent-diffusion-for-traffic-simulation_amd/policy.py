@@ -324,8 +324,6 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, d
             elif name == "agent_collision":
                 if data_batch is None or any(k not in data_batch for k in ("extent", "world_from_agent", "curr_speed")):
                     raise ValueError("agent_collision needs data_batch with extent, world_from_agent and curr_speed")
-                if prm.get("excluded_agents") is not None:
-                    raise NotImplementedError("agent_collision: excluded_agents is not built")
                 S = int(local.max()) + 1
                 key = (int(prm.get("num_disks", 5)), float(prm.get("buffer_dist", 0.2)), float(prm.get("decay_rate", 0.9)), float(prm.get("guide_moving_speed_th", 0.5)))
                 if col is None:
@@ -339,6 +337,11 @@ def guidance_from_config(guidance_config_list, scene_index, horizon: int = 52, d
                 col["weight"][si] = wgt
                 if agents is not None:
                     col["agents"][si] = list(agents)
+                if prm.get("excluded_agents") is not None:
+                    # batch indices, as upstream takes them (guidance_loss.py:447,586-593); each config's loss sees the pairs of ITS scene
+                    # only, so a listed agent of another scene changes nothing there: keep this scene's
+                    mem = set(int(b) for b in members)
+                    col.setdefault("excluded_agents", []).extend(int(b) for b in prm["excluded_agents"] if int(b) in mem)
             elif name == "map_collision":
                 need = ("extent", "raster_from_agent", "drivable_map", "curr_speed")
                 if data_batch is None or any(k not in data_batch for k in need):

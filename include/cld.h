@@ -240,7 +240,9 @@ typedef struct cld_guidance {
  * summed over the steps, averaged over ALL agents of the batch (upstream's .mean(-1) over B), zero for agents slower than
  * moving_speed_th.  total = sum over scenes of scene_weight[s] * mean over the scene's guided agents (x samples); stationary and
  * unguided agents receive no gradient (:512-534).  Agents A = B / num_samp; rows of traj are sample-minor (row = agent * num_samp
- * + sample), sample n of every agent living in scene copy n.  `excluded_agents` of upstream is not built. */
+ * + sample), sample n of every agent living in scene copy n.  `excluded`: upstream's `excluded_agents` (:447,586-593) -- a pair whose agents are BOTH
+ * flagged is not penalised.  Contract on max_scene_agents: the launch sizes its LDS and grid from it; a scene whose device-side
+ * scene_start holds MORE agents is not evaluated -- its agents get NaN values and a gradient of grad_in (or 0). */
 typedef struct cld_collision {
     const float* extent;            /* DEVICE [A,3] length, width, height                                                   */
     const float* world_from_agent;  /* DEVICE [A,3,3] row-major (rotation + translation of the agent frame in the world)     */
@@ -256,6 +258,7 @@ typedef struct cld_collision {
     float buffer_dist;              /* upstream default 0.2                                                                 */
     float decay_rate;               /* 0.9                                                                                  */
     float moving_speed_th;          /* 0.5                                                                                  */
+    const uint8_t* excluded;        /* DEVICE [A] or NULL: 1 = the agent is in the config's `excluded_agents`                */
 } cld_collision;
 
 /* The loss above on given plans: traj [B,52,6] descaled (what cld_decode returns) -> loss [B] = the per-agent values upstream

@@ -424,7 +424,8 @@ def context_encode(w: Dict[str, Tensor], image: Tensor, curr_states: Tensor, tap
 # --------------------------------------------------------------------------- #
 def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Optional[Tensor], loss_scale: Optional[Tensor],
                   lr: float, perturb_th: Optional[float], optimizer: str = "adam", speed_limit=None, acc_limit=None, target_pos=None,
-                  collision: Optional[dict] = None, grad_steps: int = 1, num_samp: int = 1, map_collision: Optional[dict] = None):
+                  collision: Optional[dict] = None, grad_steps: int = 1, num_samp: int = 1, map_collision: Optional[dict] = None,
+                  trace: Optional[list] = None):
     """One PerturbationGuidance.perturb call (guidance_loss.py:2221-2282) with decoder = `decode` and
     TargetSpeedLoss (:219-254): L = sum_b loss_scale[b] * sum_t |v_t - target| (+ optional SpeedLimitLoss / AccLimitLoss
     terms, each a (limit, per-agent scale) pair; + `collision`: the agent_collision configs, see scene_collision_total).
@@ -433,7 +434,8 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
     sqrt(v_k / (1 - 0.999^k)) + eps), whose FIRST step is -lr * g / (|g| + 1e-8); SGD's -lr * g.  perturb_th None = the
     reference's actual behaviour: its clip (:2275-2278) acts on x_guidance - x_initial, two names of one tensor
     (:2239), so it never changes anything (the golden vectors confirm); a number clips the accumulated step to +- that
-    around the initial mean, as the code intends.  Returns (guided mean, gradient of the first step)."""
+    around the initial mean, as the code intends.  Returns (guided mean, gradient of the first step); `trace` (a list) receives every
+    step's gradient."""
     def total(x):
         traj = decode(wdec, x, cond, cs, True)
         loss = traj.sum() * 0.0
@@ -470,6 +472,8 @@ def guidance_step(wdec, mean: Tensor, cond: Tensor, cs: Tensor, target_speed: Op
             (g,) = torch.autograd.grad(total(xk), xk)
         if g_first is None:
             g_first = g
+        if trace is not None:
+            trace.append(g.detach().clone())
         if optimizer == "adam":
             if grad_steps == 1:
                 delta = -lr * g / (g.abs() + 1e-8)
@@ -588,13 +592,14 @@ def transform_agents_to_world(pos: Tensor, yaw: Tensor, world_from_agent: Tensor
 
 def agent_collision_loss(x: Tensor, extent: Tensor, world_from_agent: Tensor, curr_speed: Tensor, scene_index: Tensor,
                          agt_mask: Optional[Tensor] = None, num_disks: int = 5, buffer_dist: float = 0.2, decay_rate: float = 0.9,
-                         moving_speed_th: float = 0.5) -> Tensor:
+                         moving_speed_th: float = 0.5, excluded_agents=None) -> Tensor:
     """AgentCollisionLoss.forward (src/tbsim/utils/guidance_loss.py:506-630) on x [B,N,T,6] = (x, y, v, yaw, acc, yaw-rate) in
     the agent frames -> [B,N] (rows of agt_mask when given).  Every agent is `num_disks` disks of radius width / 2 along its
     axis (:481-492); two agents of one scene collide at a step when their closest disk centres are within r_i + r_j +
     buffer_dist, the penalty is 1 - dist / that bound, weighted by decay_rate ** t (normalised), summed over the steps and
     AVERAGED over all B columns (:621), zero for agents slower than moving_speed_th (which also receive no gradient, :512-516;
-    nor do agents outside agt_mask, :523-534).  Sample n of every agent lives in scene copy n."""
+    nor do agents outside agt_mask, :523-534).  Sample n of every agent lives in scene copy n.  `excluded_agents` (batch indices,
+    :447,586-593): a pair whose agents are both listed is not penalised."""
     B, N, T_, _ = x.shape
     moving = curr_speed.abs() > moving_speed_th
     x = torch.where(moving.view(B, 1, 1, 1), x, x.detach())
@@ -611,6 +616,10 @@ def agent_collision_loss(x: Tensor, extent: Tensor, world_from_agent: Tensor, cu
     c = cent.permute(2, 1, 0, 3, 4)                                                      # [T,N,B,D,2]
     d = (c[:, :, :, None, :, None, :] - c[:, :, None, :, None, :, :]).norm(dim=-1)        # [T,N,B,B,D,D]
     pair = d.reshape(T_, N, B, B, num_disks * num_disks).min(dim=-1)[0]
+    if excluded_agents is not None:
+        ex = torch.zeros(B, dtype=torch.bool)
+        ex[torch.as_tensor(list(excluded_agents), dtype=torch.long)] = True
+        same = same & ~(ex.view(B, 1) & ex.view(1, B))
     hit = (pair <= pen_d) & same
     pen = torch.where(hit, 1.0 - pair / pen_d, torch.zeros_like(pair))
     wts = torch.tensor([decay_rate ** t for t in range(T_)], dtype=x.dtype)
@@ -660,6 +669,69 @@ def map_collision_loss(x: Tensor, extent: Tensor, raster_from_agent: Tensor, dri
     return (per_step * wts).sum(dim=-1)
 
 
+def map_collision_grad_bounds(x: Tensor, extent: Tensor, raster_from_agent: Tensor, drivable_map: Tensor, curr_speed: Tensor,
+                              row_coef: Tensor, num_points_lw=(10, 10), decay_rate: float = 0.9, moving_speed_th: float = 0.5,
+                              tie_tol: float = 1e-4):
+    """Test aid for the gradient of `map_collision_loss`: which of its elements are DEFINED by the loss and which depend on a tie.
+    An off-road sample pulls on its nearest on-road sample; on a regular sample grid two or more on-road samples can be equidistant in
+    exact arithmetic (mirror images), and torch.amin's backward then follows whichever rounding made smaller (or shares the gradient
+    among bit-equal minima; the reference's torch.cdist adds ~1e-4 m of noise of its own).  For every (plan, step) this returns the
+    interval [lo, hi] that d total / d (x, y, yaw) can take when every off-road sample may pull on ANY candidate within `tie_tol` metres
+    of its minimum, or on any mix of them -- lo == hi where no sample of the step has such a tie -- and `tied` [B,N,T], the steps that
+    have one.  Computed in float64 from the definition (:833-848), not by autograd.  x [B,N,T,6]; row_coef [B,N]: scene weight /
+    (agents of the scene x samples).  -> (lo [B,N,T,3], hi [B,N,T,3], tied [B,N,T])."""
+    x = x.double()
+    B, N, T_, _ = x.shape
+    lw = extent[:, :2].double()
+    # the sample grid and the off-road flags exactly as map_collision_loss forms them (float32: a pixel boundary must fall the same way)
+    x32 = x.float()
+    lwise, wwise = torch.linspace(-0.5, 0.5, num_points_lw[0]), torch.linspace(-0.5, 0.5, num_points_lw[1])
+    loc = torch.cartesian_prod(lwise, wwise)
+    P = loc.shape[0]
+    locs32 = loc[None] * extent[:, None, :2]
+    yaw32, pos32 = x32[..., 3], x32[..., :2]
+    c32, s32 = torch.cos(yaw32)[..., None], torch.sin(yaw32)[..., None]
+    lx32, wy32 = locs32[:, None, None, :, 0], locs32[:, None, None, :, 1]
+    pts32 = torch.stack([lx32 * c32 - wy32 * s32, lx32 * s32 + wy32 * c32], dim=-1) + pos32[..., None, :]
+    Rm, tv = raster_from_agent[:, None, None, None, :2, :2], raster_from_agent[:, None, None, None, :2, 2]
+    pix = ((Rm @ pts32.unsqueeze(-1)).squeeze(-1) + tv).long()
+    H, W = drivable_map.shape[-2:]
+    px, py = pix[..., 0].clamp(0, W - 1), pix[..., 1].clamp(0, H - 1)
+    bi = torch.arange(B).view(B, 1, 1, 1).expand(B, N, T_, P)
+    off = ~(drivable_map[bi, py, px] != 0)
+    cnt = off.sum(dim=-1)
+    overlap = (cnt != 0) & (cnt != P) & (curr_speed.abs() > moving_speed_th).view(B, 1, 1)
+    locs = loc.double()[None] * lw[:, None, :]
+    yaw, pos = x[..., 3], x[..., :2]
+    c, s_ = torch.cos(yaw)[..., None], torch.sin(yaw)[..., None]
+    lx, wy = locs[:, None, None, :, 0], locs[:, None, None, :, 1]
+    pts = torch.stack([lx * c - wy * s_, lx * s_ + wy * c], dim=-1) + pos[..., None, :]          # [B,N,T,P,2]
+    diag = (lw * lw).sum(dim=-1).sqrt().view(B, 1, 1, 1, 1)
+    e = pts[..., :, None, :] - pts[..., None, :, :]                                             # [.., i, j, 2] = p_i - p_j
+    d = e.norm(dim=-1)
+    d = torch.where(off[..., :, None], torch.full_like(d, float("inf")), d)                     # candidates i must be on road
+    dmin = d.amin(dim=-2, keepdim=True)
+    cand = d <= dmin + tie_tol                                                                   # [.., i, j]
+    use = off[..., None, :] & overlap[..., None, None]                                           # columns j: off-road samples of counted steps
+    k = -1.0 / (d.clamp(min=1e-30) * diag)
+    rel = pts - pos[..., None, :]                                                                # p_i - pos
+    gx, gy = k * e[..., 0], k * e[..., 1]
+    gw = k * (-e[..., 0] * rel[..., :, None, 1] + e[..., 1] * rel[..., :, None, 0])              # d p_i / d yaw = perp(p_i - pos)
+    wts = torch.tensor([decay_rate ** t for t in range(T_)], dtype=torch.float64)
+    wts = wts / wts.sum()
+    sc = row_coef.double().view(B, N, 1) * wts.view(1, 1, T_)
+    lo, hi = [], []
+    inf = torch.full_like(d, float("inf"))
+    for gcomp in (gx, gy, gw):
+        cmin = torch.where(cand, gcomp, inf).amin(dim=-2)                                       # per column j
+        cmax = torch.where(cand, gcomp, -inf).amax(dim=-2)
+        z = torch.zeros_like(cmin)
+        a_, b_ = torch.where(use.squeeze(-2), cmin, z).sum(dim=-1) * sc, torch.where(use.squeeze(-2), cmax, z).sum(dim=-1) * sc
+        lo.append(torch.minimum(a_, b_)); hi.append(torch.maximum(a_, b_))
+    tied = ((cand.sum(dim=-2) > 1) & use.squeeze(-2)).any(dim=-1)
+    return torch.stack(lo, dim=-1), torch.stack(hi, dim=-1), tied
+
+
 def scene_map_collision_total(traj: Tensor, mp: dict, num_samp: int = 1) -> Tensor:
     """What DiffuserGuidance.compute_guidance_loss (guidance_loss.py:2143-2172) adds for `map_collision` configs: sum over scenes
     of weight * mean over the scene's agents (and samples); mp: extent, raster_from_agent, drivable_map, curr_speed, scene_index,
@@ -681,13 +753,13 @@ def scene_collision_total(traj: Tensor, col: dict, num_samp: int = 1) -> Tensor:
     """What DiffuserGuidance.compute_guidance_loss (guidance_loss.py:2143-2172) adds to the total for `agent_collision` configs:
     sum over scenes of weight * mean over the scene's guided agents (and samples).  traj [B * num_samp, T, 6] sample-minor;
     col: extent, world_from_agent, curr_speed, scene_index, scene_weight [S] (0 = scene not guided), agents (optional dict
-    scene -> local indices), and the loss parameters."""
+    scene -> local indices), and the loss parameters (incl. excluded_agents, batch indices)."""
     BN = traj.shape[0]
     B = BN // num_samp
     x = traj.reshape(B, num_samp, traj.shape[1], 6)
     _, local = torch.unique_consecutive(col["scene_index"], return_inverse=True)
     tot = x.sum() * 0.0
-    kw = {k: col[k] for k in ("num_disks", "buffer_dist", "decay_rate", "moving_speed_th") if k in col}
+    kw = {k: col[k] for k in ("num_disks", "buffer_dist", "decay_rate", "moving_speed_th", "excluded_agents") if k in col}
     for si, wgt in enumerate(col["scene_weight"]):
         if float(wgt) == 0.0:
             continue

@@ -493,6 +493,35 @@ def section_agent_collision(ref):
                              "subset": {"weights": [1.5, 0.0], "agents": {"0": [0, 2, 3]}}}, **out)
 
 
+def section_agent_collision_excluded(ref):
+    """AgentCollisionLoss(excluded_agents=[...]) (src/tbsim/utils/guidance_loss.py:447,586-593): collisions among the listed agents
+    (batch indices) are not penalised.  Same scene and plans as `agent_collision`; scene 0 guided with agents [0, 1, 3] excluded,
+    and -- to show the list is read by batch index and masked by scene -- scene 1 guided with [1, 6, 9] excluded (1 is in scene 0)."""
+    with _refimport.redirect_stdout(_refimport.io.StringIO()):
+        import tbsim.utils.guidance_loss as gl
+    sizes, N = [6, 4], 2
+    B = sum(sizes)
+    sc = synth.make_collision_scene(sizes, IN_SEED)
+    db = {k: T(v) for k, v in sc.items()}
+    traj = T(synth.make_collision_trajectories(B, N, sc["curr_speed"], IN_SEED))
+    out = {}
+    cases = {"scene0": ([0, 1, 3], [1.0, 0.0]), "scene1": ([1, 6, 9], [0.0, 2.0])}
+    for tag, (excl, wts) in cases.items():
+        col = {"name": "agent_collision", "params": {"num_disks": 5, "buffer_dist": 0.2, "excluded_agents": excl}, "agents": None}
+        cfgs = [[dict(col, weight=wts[0])], []] if wts[0] else [[], [dict(col, weight=wts[1])]]
+        g = gl.DiffuserGuidance(cfgs)
+        x = traj.clone().requires_grad_(True)
+        tot, per = g.compute_guidance_loss(x * 1.0, db)
+        tot.backward()
+        out[f"total_{tag}"] = tot.detach().reshape(1)
+        out[f"grad_{tag}"] = x.grad.clone()
+        for k, v in per.items():
+            out[f"{tag}_{k}"] = v
+    save("agent_collision_excluded", {"scenes": sizes, "N": N, "in_seed": IN_SEED, "num_disks": 5, "buffer_dist": 0.2, "decay_rate": 0.9,
+                                      "moving_speed_th": 0.5, "scene0": {"weights": [1.0, 0.0], "excluded_agents": [0, 1, 3]},
+                                      "scene1": {"weights": [0.0, 2.0], "excluded_agents": [1, 6, 9]}}, **out)
+
+
 def section_guidance_multi(ref):
     """PerturbationGuidance.perturb (guidance_loss.py:2221-2282) with grad_steps = 3 -- torch.optim.Adam / SGD carried across the
     steps -- on the target-speed scenes of `guidance`, and with an agent_collision config (one and three steps): decoder hook =
@@ -590,7 +619,8 @@ def main():
         for name in sys.argv[1:]:
             {"cfg": section_cfg, "encoder": section_encoder, "context": section_context, "guidance": section_guidance, "reward": section_reward, "stride": section_stride, "losses": section_losses,
              "n50": section_n50, "small": section_small, "log_prob_t0": section_log_prob_t0, "select": section_select, "guide_losses": section_guide_losses,
-             "agent_collision": section_agent_collision, "guidance_multi": section_guidance_multi,
+             "agent_collision": section_agent_collision, "agent_collision_excluded": section_agent_collision_excluded,
+             "guidance_multi": section_guidance_multi,
              "map_collision": section_map_collision}[name](ref)
         return
     section_cfg(ref)
@@ -606,6 +636,7 @@ def main():
     section_select(ref)
     section_guide_losses(ref)
     section_agent_collision(ref)
+    section_agent_collision_excluded(ref)
     section_guidance_multi(ref)
     section_map_collision(ref)
 

@@ -49,6 +49,59 @@ def test_agent_collision_kernel_golden(golden, eng, tag):
         assert np.abs(grad.cpu().numpy().reshape(B, N, 52, 6)[untouched]).max() == 0.0
 
 
+@pytest.mark.parametrize("tag", ["scene0", "scene1"])
+def test_agent_collision_excluded_agents_golden(golden, eng, tag):
+    """upstream's `excluded_agents` (guidance_loss.py:447,586-593) in the kernel: values and gradient against the reference's own
+    AgentCollisionLoss(excluded_agents=...) through DiffuserGuidance + autograd; and through the policy's config adapter."""
+    from tests.test_oracle_golden import collision_inputs
+    from cld_amd.policy import guidance_from_config
+    meta, g = golden("agent_collision_excluded")
+    db = collision_inputs(meta)
+    B, N = sum(meta["scenes"]), meta["N"]
+    traj = torch.from_numpy(synth.make_collision_trajectories(B, N, db["curr_speed"].numpy(), meta["in_seed"])).reshape(B * N, 52, 6)
+    cfg = dict(_col_cfg(db, meta[tag], N), excluded_agents=meta[tag]["excluded_agents"])
+    loss, grad = eng.agent_collision(traj, cfg)
+    si = int(tag[-1])
+    per = g[f"{tag}_agent_collision_scene_{si:03d}_00"]
+    ok = ~np.isnan(per)
+    assert np.abs(loss.cpu().numpy().reshape(B, N)[ok] - per[ok]).max() <= 2e-7
+    ref = g[f"grad_{tag}"].reshape(B * N, 52, 6)
+    assert np.abs(grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+    loss0, _ = eng.agent_collision(traj, _col_cfg(db, meta[tag], N))
+    assert float((loss0 - loss).abs().max()) > 1e-3                        # the exclusion matters on this scene
+    # the same configuration as upstream writes it (a guidance config list), through the adapter
+    cfgs = [[], []]
+    cfgs[si] = [{"name": "agent_collision", "weight": meta[tag]["weights"][si], "agents": None,
+                 "params": {"num_disks": 5, "buffer_dist": 0.2, "excluded_agents": meta[tag]["excluded_agents"]}}]
+    gd = guidance_from_config(cfgs, db["scene_index"], data_batch=db)
+    loss2, grad2 = eng.agent_collision(traj, dict(gd["agent_collision"], num_samp=N))
+    assert torch.equal(loss2, loss) and torch.equal(grad2, grad)
+
+
+def test_agent_collision_scene_larger_than_declared_is_refused_not_overrun(eng):
+    """include/cld.h contract on cld_collision.max_scene_agents: a scene whose device-side scene_start holds more agents than the launch
+    was sized for is not evaluated -- NaN values, gradient = grad_in (or 0) -- and the other scenes are unaffected."""
+    import ctypes as C
+    from cld_amd import _lib
+    sizes, N = [12, 5], 1
+    B = sum(sizes)
+    sc = synth.make_collision_scene(sizes, 3, spacing=2.5)
+    db = {k: torch.from_numpy(v) for k, v in sc.items()}
+    traj = torch.from_numpy(synth.make_collision_trajectories(B, N, sc["curr_speed"], 3)).reshape(B, 52, 6).cuda()
+    good_loss, good_grad = eng.agent_collision(traj, dict(extent=db["extent"], world_from_agent=db["world_from_agent"], curr_speed=db["curr_speed"],
+                                                          scene_index=db["scene_index"], weight=[1.0, 1.0]))
+    cc, keep = eng._collision(dict(extent=db["extent"], world_from_agent=db["world_from_agent"], curr_speed=db["curr_speed"],
+                                   scene_index=db["scene_index"], weight=[1.0, 1.0]), B)
+    cc.max_scene_agents = 8                                            # a caller that under-declares the 12-agent scene
+    gin = torch.randn(B, 52, 6, device="cuda")
+    loss = torch.zeros(B, device="cuda"); grad = torch.full((B, 52, 6), 7.0, device="cuda")
+    eng._check(eng.lib.cld_agent_collision(eng._h, C.c_void_p(traj.data_ptr()), C.byref(cc), C.c_void_p(gin.data_ptr()), C.c_void_p(loss.data_ptr()),
+                                           C.c_void_p(grad.data_ptr()), B, eng._stream()), "cld_agent_collision")
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(loss[:12]).all()) and torch.equal(grad[:12], gin[:12])
+    assert torch.equal(loss[12:], good_loss[12:]) and float((grad[12:] - (good_grad[12:] + gin[12:])).abs().max()) <= 1e-6
+
+
 def test_agent_collision_kernel_vs_oracle_at_scene_size(eng):
     """Two 64-agent scenes (the unit BASELINE's configs name) + a 5-agent one, 2 samples, both big scenes guided with different
     weights: values and gradient against the oracle's autograd; grad_in is added; deterministic."""
@@ -97,8 +150,29 @@ def test_guidance_multi_step_and_collision_golden(golden, eng, case, kernel):
     finally:
         eng.force_kernel("guide", "auto")
     err = np.abs(xg.cpu().numpy() - g[f"guided_{case}"])
-    if opt == "adam":      # sign-like steps where a gradient element is ~1e-8 (see tests/test_oracle_golden.py): a handful of elements, bounded
-        assert (err > 2e-4).mean() <= 2e-3 and err.max() <= 3.5 * lr
+    if opt == "adam":
+        # Adam's normalised step is sign-like where a gradient element is within rounding of zero: THERE an element may land up to lr per
+        # step (3.5 lr with the bias corrections) from the reference; nowhere else.  Which elements those are is not assumed: the fp64
+        # oracle's gradient of every one of the steps says so (flag = some step's |g| within 5 x the gradient tolerance 2e-5 max|g| that
+        # tests/guided_checks.py holds the kernel to, or exactly zero).  Every element outside the flagged set must match to rounding.
+        from oracle import cld_oracle as O
+        wd64 = {k: v.double() for k, v in O.to_torch(synth.make_decoder_weights(meta["w_seed"])).items()}
+        d = lambda t: t.double()
+        tr = []
+        kw = dict(grad_steps=steps, trace=tr)
+        if case.startswith("ts_"):
+            O.guidance_step(wd64, d(mean), d(cond), d(cs), d(tgt), d(ts_scale), lr, None, opt, **kw)
+        else:
+            c64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in col.items()}
+            c64["scene_weight"] = meta["col_weights"]
+            O.guidance_step(wd64, d(mean), d(cond), d(cs), d(tgt), d(col_ts_scale), lr, None, opt, collision=c64, **kw)
+        G = torch.stack(tr).abs()                                       # [steps, B, 52, 4]
+        flagged = (G.min(dim=0)[0] <= 1e-4 * float(G.max())).numpy()
+        big = err > 2e-4
+        print(f"   [{case}/{kernel}] elements flagged as near-zero-gradient: {int(flagged.sum())} of {flagged.size}; beyond rounding: {int(big.sum())} "
+              f"(all flagged: {bool((~big | flagged).all())}); max err unflagged {err[~flagged].max():.2e}, flagged {err[flagged].max() if flagged.any() else 0.0:.2e}")
+        assert (~big | flagged).all(), "an element whose gradient is well away from zero at every step differs from the reference"
+        assert err.max() <= 3.5 * lr
     else:
         assert err.max() <= 2e-4 * max(1.0, float(np.abs(g[f"guided_{case}"] - mean.numpy()).max()))
     assert np.abs(g[f"guided_{case}"] - mean.numpy()).max() > 1e-3
@@ -222,7 +296,24 @@ def test_map_collision_kernel_golden(golden, eng):
     loss, grad = eng.map_collision(traj, _map_cfg(db, meta["weight"], N))
     assert np.abs(loss.cpu().numpy().reshape(B, N) - g["values"]).max() <= 2e-5
     ref = g["grad"].reshape(B * N, 52, 6)
-    assert np.abs(grad.cpu().numpy() - ref).max() <= 1e-2 * np.abs(ref).max()
+    # No blanket percentage: the oracle says which (plan, step) elements the loss DEFINES and which hang on a tie between equidistant
+    # on-road samples (O.map_collision_grad_bounds: the interval a tie admits; lo == hi elsewhere).  Untied steps are held to the
+    # reference's own gradient, tied ones to the interval; the reference's gradient itself lies in it (checked: its cdist noise only
+    # ever decided ties).
+    from oracle import cld_oracle as O
+    coef = torch.full((B, N), float(meta["weight"]) / (B * N))
+    lo, hi, tied = O.map_collision_grad_bounds(traj.reshape(B, N, 52, 6), db["extent"], db["raster_from_agent"], db["drivable_map"], db["curr_speed"], coef)
+    got = grad.cpu().double().reshape(B, N, 52, 6)
+    gmax = float(np.abs(ref).max())
+    assert float(got[..., [2, 4, 5]].abs().max()) == 0.0
+    out = torch.maximum(lo - got[..., [0, 1, 3]], got[..., [0, 1, 3]] - hi).clamp(min=0)
+    refo = torch.from_numpy(ref).double().reshape(B, N, 52, 6)[..., [0, 1, 3]]
+    d_ref = (got[..., [0, 1, 3]] - refo).abs()
+    print(f"map-collision gradient vs the reference: untied steps max {float(d_ref[~tied].max()) / gmax:.2e} of max|g|; {int(tied.sum())} tied steps, "
+          f"outside their interval by {float(out[tied].max()) / gmax if tied.any() else 0.0:.2e}")
+    assert float(torch.maximum(lo - refo, refo - hi).max()) <= 1e-4 * gmax          # the reference's own gradient is inside the interval
+    assert float(d_ref[~tied].max()) <= 1e-3 * gmax
+    assert float(out.max()) <= 1e-3 * gmax
     gm = meta["guided"]
     B2 = gm["B"]
     inp = synth.make_inputs(B2, meta["in_seed"])
@@ -242,14 +333,15 @@ def test_map_collision_kernel_golden(golden, eng):
         assert np.abs(xg.cpu().numpy() - g["guided_map_sgd1"]).max() <= 1e-2 * moved, kernel
 
 
-@pytest.mark.parametrize("grid,gtol", [((1, 16), 2e-4), ((14, 1), 0.15), ((12, 6), 0.15)])
-def test_map_collision_kernel_vs_oracle_multi_scene(eng, grid, gtol):
+@pytest.mark.parametrize("grid", [(1, 16), (14, 1), (12, 6)])
+def test_map_collision_kernel_vs_oracle_multi_scene(eng, grid):
     """Three scenes (40 + 7 + 30 agents, 2 samples, one scene unguided): values against the oracle to rounding, deterministic,
-    grad_in added.  The gradient is compared tightly on a sample line ACROSS the box (the road is a band along the heading, so every
-    off-road point has one nearest on-road point); along the box and on a two-dimensional grid isolated off-road samples sit between
-    mirror-image on-road neighbours that are equidistant in exact arithmetic: torch shares the gradient among the minima it finds
-    bit-equal and otherwise takes whichever rounding made smaller (the reference's cdist adds 1e-4 m of noise of its own), the kernel
-    shares it among candidates within 1e-5 -- so there the gradients are only required to agree in the large."""
+    grad_in added.  The gradient, element by element: along the box and on a two-dimensional grid an isolated off-road sample can sit
+    between mirror-image on-road neighbours that are equidistant in exact arithmetic -- torch shares the gradient among the minima it
+    finds bit-equal and otherwise takes whichever rounding made smaller, the kernel shares it among candidates within 1e-5.  The
+    oracle separates the two kinds of element (O.map_collision_grad_bounds): steps without such a tie (every off-road sample's two
+    nearest on-road samples more than 1e-4 m apart in distance) must match the oracle's autograd to 1e-3 of max|g|; steps with one
+    must lie in the interval the tied candidates span (+ the same 1e-3).  No element is exempt."""
     from oracle import cld_oracle as O
     sizes, N = [40, 7, 30], 2
     B = sum(sizes)
@@ -266,7 +358,21 @@ def test_map_collision_kernel_vs_oracle_multi_scene(eng, grid, gtol):
     loss, grad = eng.map_collision(traj, cfg)
     assert float(vref.max()) > 0.5 and float(gref.abs().max()) > 0.0
     assert float((loss.cpu() - vref).abs().max()) <= 2e-5 * max(1.0, float(vref.max()))
-    assert float((grad.cpu() - gref).abs().max()) <= gtol * float(gref.abs().max())
+    _, local = torch.unique_consecutive(db["scene_index"], return_inverse=True)
+    coef = torch.tensor([wts[int(local[b])] / (sizes[int(local[b])] * N) for b in range(B)]).view(B, 1).expand(B, N)
+    lo, hi, tied = O.map_collision_grad_bounds(traj.reshape(B, N, 52, 6), db["extent"], db["raster_from_agent"], db["drivable_map"], db["curr_speed"],
+                                               coef, num_points_lw=grid)
+    gmax = float(gref.abs().max())
+    got = grad.cpu().double().reshape(B, N, 52, 6)[..., [0, 1, 3]]
+    ref3 = gref.double().reshape(B, N, 52, 6)[..., [0, 1, 3]]
+    assert float(grad.cpu().reshape(B, N, 52, 6)[..., [2, 4, 5]].abs().max()) == 0.0
+    assert float(torch.maximum(lo - ref3, ref3 - hi).max()) <= 1e-5 * gmax            # the oracle's own autograd gradient lies in its intervals
+    out = torch.maximum(lo - got, got - hi).clamp(min=0)
+    d_un = (got - ref3).abs()[~tied]
+    print(f"grid {grid}: {int(tied.sum())} of {tied.numel()} (plan, step) pairs hang on a tie; untied: max |d| = {float(d_un.max()) / gmax:.2e} of max|g|; "
+          f"tied: outside the interval by {float(out[tied].max()) / gmax if tied.any() else 0.0:.2e}, interval width up to {float((hi - lo).max()) / gmax:.2e}")
+    assert float(d_un.max()) <= 1e-3 * gmax
+    assert float(out.max()) <= 1e-3 * gmax
     gin = torch.randn(B * N, 52, 6)
     _, grad2 = eng.map_collision(traj, cfg, grad_in=gin)
     assert float((grad2.cpu() - (grad.cpu() + gin)).abs().max()) <= 1e-6
@@ -305,3 +411,49 @@ def test_sampling_step_with_both_collision_terms_vs_oracle(eng):
     assert float((got["mean_guided"].cpu() - ref).abs().max()) <= 2e-4 * sc_
     assert float((got["x_next"].cpu() - (ref + sigma * z)).abs().max()) <= 2e-4 * sc_
     assert float((ref - mean).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("sizes", [[64, 64, 64, 64], [64] * 8])
+def test_collision_guided_step_at_the_batch_sizes_that_take_the_forward_sweep_path(eng, sizes):
+    """From 256 rows a collision- / map-guided optimiser step decodes the current iterate with the guidance kernel's OWN forward sweep
+    (guide_quad_kernel stopped behind its forward half, actions parked in the gradient buffer) + the O(T) roll-out kernel with scaled
+    input, instead of cld_decode's kernel (csrc/cld_api.hip run_guidance) -- the default at the headline's 2,048 agents.  Checked here at
+    256 and 512 agents (4 / 8 scenes of 64): the guided mean of the automatic path against the same step with the decoder forced
+    (which takes launch_decode), <= 1e-5 of the mean's scale, and -- at 256 agents -- against the oracle's autograd restatement."""
+    from oracle import cld_oracle as O
+    B = sum(sizes)
+    inp = synth.make_inputs(B, 31)
+    cond, cs = torch.from_numpy(inp["cond_feat"]), torch.from_numpy(inp["curr_states"])
+    sc = synth.make_collision_scene(sizes, 31, spacing=3.0)
+    sc["curr_speed"] = inp["curr_states"][:, 2].copy()
+    db = {k: torch.from_numpy(v) for k, v in sc.items()}
+    ms = synth.make_map_scene(B, 33, half_width_m=(0.6, 1.4))
+    mdb = {k: torch.from_numpy(v) for k, v in ms.items()}
+    mdb["curr_speed"], mdb["scene_index"] = db["curr_speed"], db["scene_index"]
+    mean = torch.from_numpy(synth.normal(31, "fwd_path_mean", (B, 52, 4))) * 0.7
+    tgt = torch.from_numpy(synth.uniform(31, "fwd_path_tgt", (B, 52), 0.0, 12.0))
+    scale = torch.full((B,), 1.0 / (64 * 52))
+    S = len(sizes)
+    wcol, wmap = [40.0 + 5.0 * s for s in range(S)], [0.3 + 0.05 * s for s in range(S)]
+    gd = dict(curr_states=cs, target_speed=tgt, loss_scale=scale, lr=5.0, optimizer="sgd", grad_steps=2,
+              agent_collision=dict(extent=db["extent"], world_from_agent=db["world_from_agent"], curr_speed=db["curr_speed"],
+                                   scene_index=db["scene_index"], weight=wcol),
+              map_collision=dict(_map_cfg(mdb, wmap), scene_index=db["scene_index"]))
+    auto = eng.guidance_step(mean, cond, gd, sigma=0.3).clone()
+    eng.force_kernel("decode", "mfma")
+    try:
+        forced = eng.guidance_step(mean, cond, gd, sigma=0.3).clone()
+    finally:
+        eng.force_kernel("decode", "auto")
+    sc_ = max(1.0, float(mean.abs().max()))
+    moved = float((auto.cpu() - mean).abs().max())
+    d = float((auto - forced).abs().max())
+    print(f"forward-sweep decode path vs launch_decode at {B} agents: max|d| = {d:.3e}; the guided step moved the mean by {moved:.3e}")
+    assert moved > 1e-3 and d <= 1e-5 * sc_
+    if B == 256:
+        wd = O.to_torch(synth.make_decoder_weights(0))
+        ref, _ = O.guidance_step(wd, mean, cond, cs, tgt, scale, 5.0, None, "sgd", collision=dict(db, scene_weight=wcol),
+                                 grad_steps=2, map_collision=dict(mdb, scene_weight=wmap))
+        err = float((auto.cpu() - ref).abs().max())
+        print(f"   vs the oracle: {err:.3e}")
+        assert err <= 2e-4 * sc_

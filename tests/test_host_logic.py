@@ -186,8 +186,11 @@ def test_guidance_struct_matches_header():
     assert g.grad_steps.offset == 116 and g.guide_clean.offset == 124 and g.collision.offset == 128      # appended in round 3: the earlier layout is untouched
     c = _lib.CldCollision
     assert [n for n, _ in c._fields_] == ["extent", "world_from_agent", "curr_speed", "scene_start", "scene_weight", "guided", "num_scenes",
-                                          "num_samp", "num_disks", "max_scene_agents", "buffer_dist", "decay_rate", "moving_speed_th"]
-    assert ctypes.sizeof(c) == 80 and c.num_scenes.offset == 48 and c.buffer_dist.offset == 64
+                                          "num_samp", "num_disks", "max_scene_agents", "buffer_dist", "decay_rate", "moving_speed_th", "excluded"]
+    assert ctypes.sizeof(c) == 88 and c.num_scenes.offset == 48 and c.buffer_dist.offset == 64 and c.excluded.offset == 80      # `excluded` appended in round 4
+    cbody = open(os.path.join(ROOT, "include", "cld.h")).read()
+    cbody = cbody[cbody.index("typedef struct cld_collision {"):cbody.index("} cld_collision;")]
+    assert re.findall(r"^\s+(?:const\s+)?\w+\*?\s+\*?(\w+);", cbody, re.M) == [n for n, _ in c._fields_]
     m = _lib.CldMapCollision
     assert ctypes.sizeof(m) == 80 and m.num_scenes.offset == 48 and m.decay_rate.offset == 72
     hdr = open(os.path.join(ROOT, "include", "cld.h")).read()

@@ -471,6 +471,31 @@ def test_agent_collision_loss_vs_reference(golden, tag):
         assert np.abs(g["grad_subset"][untouched]).max() == 0.0 and np.abs(grad.reshape(B, N, 52, 6).numpy()[untouched]).max() == 0.0
 
 
+@pytest.mark.parametrize("tag", ["scene0", "scene1"])
+def test_agent_collision_excluded_agents_vs_reference(golden, tag):
+    """AgentCollisionLoss(excluded_agents=...) of the reference (guidance_loss.py:447,586-593; make_golden.section_agent_collision_excluded):
+    pairs whose agents are both listed (batch indices) are not penalised -- values, total and gradient; in `scene1` one listed agent
+    belongs to the other scene and changes nothing there.  The exclusion does change the result (against golden `agent_collision`)."""
+    meta, g = golden("agent_collision_excluded")
+    base_meta, base = golden("agent_collision")
+    db = collision_inputs(meta)
+    B, N = sum(meta["scenes"]), meta["N"]
+    traj = torch.from_numpy(synth.make_collision_trajectories(B, N, db["curr_speed"].numpy(), meta["in_seed"]))
+    col = dict(db, scene_weight=meta[tag]["weights"], excluded_agents=meta[tag]["excluded_agents"])
+    x = traj.reshape(B * N, 52, 6).clone().requires_grad_(True)
+    tot = O.scene_collision_total(x, col, N)
+    (grad,) = torch.autograd.grad(tot, x)
+    assert abs(float(tot) - float(g[f"total_{tag}"][0])) <= 1e-7
+    assert np.abs(grad.reshape(B, N, 52, 6).numpy() - g[f"grad_{tag}"]).max() <= 2e-7 * max(1.0, 1e3 * np.abs(g[f"grad_{tag}"]).max())
+    si = int(tag[-1])
+    per = g[f"{tag}_agent_collision_scene_{si:03d}_00"]
+    ok = ~np.isnan(per)
+    vals = O.agent_collision_loss(traj, db["extent"], db["world_from_agent"], db["curr_speed"], db["scene_index"],
+                                  excluded_agents=meta[tag]["excluded_agents"]).numpy()
+    assert np.abs(vals[ok] - per[ok]).max() <= 1e-7
+    assert abs(float(g[f"total_{tag}"][0]) - float(base["total_all" if si == 0 else "total_scene1"][0])) > 1e-4
+
+
 def guidance_multi_inputs(meta):
     B = meta["B"]
     inp = synth.make_inputs(B, meta["in_seed"])
