@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
     float* gnw = gn + wave * 256;
     CSTAMP(0);
     CSTAMP_RT(14);
+#ifdef CLD_CHAIN_STAGGER      // experiment builds only: second-slot workgroups of the first generation start n x 8k cycles late (no gain)
+    if (((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
+        for (int k_ = 0; k_ < CLD_CHAIN_STAGGER; ++k_) __builtin_amdgcn_s_sleep(127);
+#endif
 
     // V addressing: rows of 64 channels = 16 slots of 16 bytes, slot s of row r at s ^ (r & 15): the four 16-lane groups of a ds_read_b128
     // then touch every bank once.  Fragment of chunk c: slot 4 c + kk; this lane's own channels: slot 4 wave + kk.

@@ -276,7 +276,6 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
         al[m] = G::TPA == 4 ? r >> 2 : r / G::TPA;
         tl[m] = G::TPA == 4 ? r & 3 : r % G::TPA;
     }
-    auto live = [&](const int m, const int o) { return (ROWS == 16 * NM || 16 * m + i16 < ROWS) && 4 * tl[m] + o < L; };
     v4f Y[NM][4];                                         // [m][o]
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
@@ -368,38 +367,55 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
             __builtin_amdgcn_wave_barrier();
         }
     };
+    // The arithmetic below runs on register PAIRS (v_pk_add / mul / fma_f32): with both workgroups of a CU in their epilogues the phase is
+    // bound by VALU issue (scripts/ubench/mfma_covalu.hip).  Outputs past the agent's end exist only in an agent's last tile (L = 13: its
+    // outputs 1..3; L = 26: 2, 3): they are zeroed by a factor per row instead of a select per value, and an idle row needs no guard at all
+    // -- its sums are never read and its stores fall outside the buffer's range.
+    constexpr int NDEAD = 4 * G::TPA - L;
+    auto lo2 = [](const v4f v) { return __builtin_shufflevector(v, v, 0, 1); };
+    auto hi2 = [](const v4f v) { return __builtin_shufflevector(v, v, 2, 3); };
+    auto cat2 = [](const v2f a, const v2f b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3); };
+    float tailf[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) tailf[m] = tl[m] == G::TPA - 1 ? 0.f : 1.f;
     float mean[NM], s2[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        float sv = 0.f;
+        v2f sv = {0.f, 0.f};
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (live(m, o)) sv += (Y[m][o][0] + Y[m][o][1]) + (Y[m][o][2] + Y[m][o][3]);
-        mean[m] = sv;
+        for (int o = 0; o < 4; ++o) {
+            if (o >= 4 - NDEAD) Y[m][o] = cat2(lo2(Y[m][o]) * tailf[m], hi2(Y[m][o]) * tailf[m]);
+            sv += lo2(Y[m][o]);
+            sv += hi2(Y[m][o]);
+        }
+        mean[m] = sv[0] + sv[1];
     }
     group_totals(mean, xch);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
         mean[m] *= inv;
-        float sv = 0.f;
+        const v2f mm = {mean[m], mean[m]};
+        v2f q = {0.f, 0.f};
 #pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (live(m, o)) {
-                const v4f dv = Y[m][o] - mean[m];
-                sv += __builtin_fmaf(dv[0], dv[0], dv[1] * dv[1]) + __builtin_fmaf(dv[2], dv[2], dv[3] * dv[3]);
-            }
-        s2[m] = sv;
+        for (int o = 0; o < 4; ++o) {
+            v2f d0 = lo2(Y[m][o]) - mm, d1 = hi2(Y[m][o]) - mm;
+            if (o >= 4 - NDEAD) { d0 *= tailf[m]; d1 *= tailf[m]; }
+            q = __builtin_elementwise_fma(d0, d0, q);
+            q = __builtin_elementwise_fma(d1, d1, q);
+        }
+        s2[m] = q[0] + q[1];
     }
     group_totals(s2, xch + G::XCH / 2);
     W1STAMP(3);
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
+        // (Y - mean) sc + beta = Y sc + (beta - mean sc)
         const v4f sc = (1.0f / sqrtf(s2[m] * inv + 1e-5f)) * gam;
+        const v4f sh = __builtin_elementwise_fma(sc, v4f{-mean[m], -mean[m], -mean[m], -mean[m]}, bet);
         const v4f add = tb + cbv[m];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            const v4f x = __builtin_elementwise_fma(Y[m][o] - mean[m], sc, bet);
-            v4f v = mish4(x) + add;
+            v4f v = mish4(__builtin_elementwise_fma(Y[m][o], sc, sh)) + add;
             if (has_res) v += rv[m][o];
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rsy, ooff[m][o], 0, 0);
         }

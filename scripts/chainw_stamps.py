@@ -27,5 +27,9 @@ print(f"Winograd head chain: {len(s)} workgroups; kernel span {s[:,9].max()-t0} 
 print(f"   MFMA issue per wave: {80 + 3 * 512 + 336} x 32 = {(80 + 3 * 512 + 336) * 32} cycles")
 for k, nme in enumerate(names):
     print(f"   {nme:36s} mean {d[:,k].mean():9.0f}  min {d[:,k].min():8d}  max {d[:,k].max():8d}")
+for lo_, hi_, tag in ((0, 256, "ids 0..255 (first slot of a CU)"), (256, 512, "ids 256..511 (second slot)"), (512, 1024, "ids 512.. (second generation)")):
+    if len(s) >= hi_:
+        dd = d[lo_:hi_]
+        print(f"   {tag}: life {(s[lo_:hi_, 9] - s[lo_:hi_, 0]).mean():.0f}; phases " + " ".join(f"{dd[:, k].mean():.0f}" for k in range(9)))
 st = np.sort(s[:, 0] - t0)
 print("   workgroup start times (cycles), every 64th:", st[::64].tolist())

@@ -68,7 +68,7 @@ def test_agent_collision_excluded_agents_golden(golden, eng, tag):
     ref = g[f"grad_{tag}"].reshape(B * N, 52, 6)
     assert np.abs(grad.cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
     loss0, _ = eng.agent_collision(traj, _col_cfg(db, meta[tag], N))
-    assert float((loss0 - loss).abs().max()) > 1e-3                        # the exclusion matters on this scene
+    assert float((loss0 - loss).abs().max()) > 5e-4                        # the exclusion matters on this scene
     # the same configuration as upstream writes it (a guidance config list), through the adapter
     cfgs = [[], []]
     cfgs[si] = [{"name": "agent_collision", "weight": meta[tag]["weights"][si], "agents": None,
@@ -449,7 +449,7 @@ def test_collision_guided_step_at_the_batch_sizes_that_take_the_forward_sweep_pa
     moved = float((auto.cpu() - mean).abs().max())
     d = float((auto - forced).abs().max())
     print(f"forward-sweep decode path vs launch_decode at {B} agents: max|d| = {d:.3e}; the guided step moved the mean by {moved:.3e}")
-    assert moved > 1e-3 and d <= 1e-5 * sc_
+    assert moved > 3e-4 and d <= 1e-5 * sc_
     if B == 256:
         wd = O.to_torch(synth.make_decoder_weights(0))
         ref, _ = O.guidance_step(wd, mean, cond, cs, tgt, scale, 5.0, None, "sgd", collision=dict(db, scene_weight=wcol),
