@@ -206,8 +206,34 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 constexpr int kMapWaves = 13;                           // 13 waves x 4 steps = the 52 steps of a plan
+
+// nearest on-road candidate(s) of one off-road sample, as a mergeable partial result: the smallest squared distance seen and, over the
+// candidates within 1e-5 (relative) of it, the sums the gradient needs.  On a regular grid mirror-image candidates are equidistant in
+// exact arithmetic (an isolated off-road sample between two on-road neighbours): torch.amin's backward shares the gradient evenly among
+// the minima it finds equal, which for mirror images cancels the translation part.  Candidates within 1e-5 of the minimum are treated as
+// that tie -- the symmetric choice, instead of whichever rounding favours.
+struct Nearest {
+    float best, sx, sy, sw, cnt;
+    __device__ __forceinline__ void init() { best = 3.0e38f; sx = sy = sw = cnt = 0.f; }
+    __device__ __forceinline__ void add(float d2, float ex, float ey, float w) {
+        if (d2 > best * (1.0f + 1e-5f)) return;
+        if (d2 < best * (1.0f - 1e-5f)) { sx = 0.f; sy = 0.f; sw = 0.f; cnt = 0.f; }
+        best = fminf(best, d2);
+        sx += ex; sy += ey; sw += w; cnt += 1.f;
+    }
+    __device__ __forceinline__ void merge(float ob, float ox, float oy, float ow, float oc) {      // another lane's partial result
+        if (ob > best * (1.0f + 1e-5f)) return;
+        if (ob < best * (1.0f - 1e-5f)) { sx = 0.f; sy = 0.f; sw = 0.f; cnt = 0.f; }
+        best = fminf(best, ob);
+        sx += ox; sy += oy; sw += ow; cnt += oc;
+    }
+};
+
 __global__ __launch_bounds__(64 * kMapWaves) void map_collision_kernel(const MapCollisionArgs p) {
-    __shared__ float4 pts[kMapWaves][kMaxPts];          // per wave: x, y (agent frame), off-road flag
+    // per wave: the step's ON-road samples and OFF-road samples (x, y in the agent frame), compacted -- the search of an
+    // off-road sample walks on-road candidates only, and the off-road samples fill the lanes from 0
+    __shared__ float2 on_pts[kMapWaves][kMaxPts];
+    __shared__ float2 off_pts[kMapWaves][kMaxPts];
     __shared__ float part[TT];
     __shared__ float s_coef;
     const int row = blockIdx.x, b = row / p.num_samp;
@@ -235,49 +261,59 @@ __global__ __launch_bounds__(64 * kMapWaves) void map_collision_kernel(const Map
         const float px = x[0], py = x[1];
         float sy, cy;
         sincosf(x[3], &sy, &cy);
-        int n_off = 0;
-        for (int k = lane; k < P; k += 64) {
-            const float lx = unit_linspace(k / p.num_points_w, p.num_points_l) * len, wy = unit_linspace(k % p.num_points_w, p.num_points_w) * wid;
-            const float ax = lx * cy - wy * sy + px, ay = lx * sy + wy * cy + py;
-            int ix = (int)(R[0] * ax + R[1] * ay + R[2]), iy = (int)(R[3] * ax + R[4] * ay + R[5]);      // .long(): truncation toward zero
-            ix = min(max(ix, 0), p.W - 1); iy = min(max(iy, 0), p.H - 1);
-            const bool off = dm[(size_t)iy * p.W + ix] == 0;
-            pts[wave][k] = make_float4(ax, ay, off ? 1.f : 0.f, 0.f);
-            n_off += off ? 1 : 0;
+        int n_on = 0, n_off = 0;                        // (wave-uniform)
+        for (int k0 = 0; k0 < P; k0 += 64) {
+            const int k = k0 + lane;
+            bool off = false, valid = k < P;
+            float ax = 0.f, ay = 0.f;
+            if (valid) {
+                const float lx = unit_linspace(k / p.num_points_w, p.num_points_l) * len, wy = unit_linspace(k % p.num_points_w, p.num_points_w) * wid;
+                ax = lx * cy - wy * sy + px; ay = lx * sy + wy * cy + py;
+                int ix = (int)(R[0] * ax + R[1] * ay + R[2]), iy = (int)(R[3] * ax + R[4] * ay + R[5]);      // .long(): truncation toward zero
+                ix = min(max(ix, 0), p.W - 1); iy = min(max(iy, 0), p.H - 1);
+                off = dm[(size_t)iy * p.W + ix] == 0;
+            }
+            // compaction in sample order (the order the candidates are walked in decides nothing but rounding-level ties)
+            const unsigned long long m_off = __ballot(valid && off), m_on = __ballot(valid && !off);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (valid && off) off_pts[wave][n_off + __popcll(m_off & below)] = make_float2(ax, ay);
+            if (valid && !off) on_pts[wave][n_on + __popcll(m_on & below)] = make_float2(ax, ay);
+            n_off += __popcll(m_off); n_on += __popcll(m_on);
         }
-        n_off = (int)wave_sum((float)n_off);
-        __syncthreads();                                // (every wave runs the same 4 iterations) the points are visible to all lanes
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): the wave's own LDS writes have landed; the lists are wave-private
+        __builtin_amdgcn_wave_barrier();
         float loss = 0.f, gx = 0.f, gy = 0.f, gyaw = 0.f;
-        if (n_off != 0 && n_off != P && moving) {
-            for (int j = lane; j < P; j += 64) {
-                const float4 pj = pts[wave][j];
-                if (pj.z == 0.f) continue;
-                // nearest on-road point.  On a regular grid mirror-image candidates are equidistant in exact arithmetic (an isolated
-                // off-road sample between two on-road neighbours): torch.amin's backward shares the gradient evenly among the minima
-                // it finds equal, which for mirror images cancels the translation part.  Candidates within 1e-5 (relative, squared
-                // distance) of the minimum are treated as that tie -- the symmetric choice, instead of whichever rounding favours.
-                // (one pass: candidates within 1e-5 of the running minimum accumulate; a clearly smaller one starts over)
-                float best = 3.0e38f, sx = 0.f, sy = 0.f, sw = 0.f, cnt = 0.f;
-                for (int i = 0; i < P; ++i) {
-                    const float4 pi = pts[wave][i];
-                    if (pi.z != 0.f) continue;
-                    const float ex = pi.x - pj.x, ey = pi.y - pj.y, d2 = ex * ex + ey * ey;
-                    if (d2 > best * (1.0f + 1e-5f)) continue;
-                    if (d2 < best * (1.0f - 1e-5f)) { sx = 0.f; sy = 0.f; sw = 0.f; cnt = 0.f; }
-                    best = fminf(best, d2);
-                    sx += ex; sy += ey; cnt += 1.f;
-                    sw += -ex * (pi.y - py) + ey * (pi.x - px);            // d p_i / d yaw = perp(p_i - pos)
+        if (n_off != 0 && n_on != 0 && moving) {
+            // lanes = (off-road sample jj, part): JN = n_off rounded up to a power of two (<= 64) samples side by side, the 64 / JN parts
+            // of a sample take every (64 / JN)-th candidate each and merge their partial results across lanes (lane ^ JN, ^ 2 JN, ...)
+            int JN = 1;
+            while (JN < n_off && JN < 64) JN <<= 1;
+            const int S = 64 / JN, jl = lane & (JN - 1), prt = lane / JN;
+            for (int j0 = 0; j0 < n_off; j0 += JN) {
+                const int j = j0 + jl;
+                const bool act = j < n_off;
+                const float2 pj = off_pts[wave][act ? j : 0];
+                Nearest nr;
+                nr.init();
+                for (int i = prt; i < n_on; i += S) {
+                    const float2 pi = on_pts[wave][i];
+                    const float ex = pi.x - pj.x, ey = pi.y - pj.y;
+                    nr.add(ex * ex + ey * ey, ex, ey, -ex * (pi.y - py) + ey * (pi.x - px));      // d p_i / d yaw = perp(p_i - pos)
                 }
-                const float d = sqrtf(best);
-                loss += 1.0f - d * inv_diag;
-                if (d > 0.f) {
-                    const float k = -inv_diag / (d * cnt);
-                    gx += k * sx; gy += k * sy; gyaw += k * sw;
+                for (int o = JN; o < 64; o <<= 1)
+                    nr.merge(__shfl_xor(nr.best, o), __shfl_xor(nr.sx, o), __shfl_xor(nr.sy, o), __shfl_xor(nr.sw, o), __shfl_xor(nr.cnt, o));
+                if (act && prt == 0) {
+                    const float d = sqrtf(nr.best);
+                    loss += 1.0f - d * inv_diag;
+                    if (d > 0.f) {
+                        const float k = -inv_diag / (d * nr.cnt);
+                        gx += k * nr.sx; gy += k * nr.sy; gyaw += k * nr.sw;
+                    }
                 }
             }
         }
         loss = wave_sum(loss); gx = wave_sum(gx); gy = wave_sum(gy); gyaw = wave_sum(gyaw);
-        __syncthreads();                                // nobody still reads the points the next step overwrites
+        __builtin_amdgcn_wave_barrier();                // nobody still reads the lists the next step overwrites
         const float wt = powf(p.decay_rate, (float)t) / wsum;
         if (lane == 0) {
             part[t] = loss * wt;
