@@ -382,9 +382,10 @@ struct Ws {
     float *xw, *xtmp, *meanb, *cb, *buf[NBUF], *guide;
     float *gcur, *adam_m, *adam_v;      // multi-step guidance: current iterate and Adam moments [b_pad,52,4] each
     float *col_traj, *col_grad;         // collision term: decoded plans and d total / d plans [b_pad,52,6] each
+    float* col_act;                     // ... and the decoder's scaled actions [b_pad,52,2] of the forward launch of a split guidance step
 };
 size_t ws_floats(int b_pad) {
-    return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT) + guide_scratch_floats(b_pad) + (size_t)b_pad * (3 * T * D + 2 * T * 6);
+    return (size_t)b_pad * (3 * T * D + NCB + (size_t)NBUF * ACT) + guide_scratch_floats(b_pad) + (size_t)b_pad * (3 * T * D + 2 * T * 6 + T * 2);
 }
 Ws carve(void* ws, int b_pad) {
     Ws w;
@@ -399,7 +400,8 @@ Ws carve(void* ws, int b_pad) {
     w.adam_m = p; p += (size_t)b_pad * T * D;
     w.adam_v = p; p += (size_t)b_pad * T * D;
     w.col_traj = p; p += (size_t)b_pad * T * 6;
-    w.col_grad = p;
+    w.col_grad = p; p += (size_t)b_pad * T * 6;
+    w.col_act = p;
     return w;
 }
 inline int pad16(int b) { return (b + 15) / 16 * 16; }
@@ -1412,11 +1414,14 @@ static int run_guidance(cld_handle h, const Ws& w, const cld_guidance* gd, int B
                 // (from the batch size at which cld_decode itself would take its 16-agent MFMA form, ~0.3 ms; below that the
                 //  one-agent-per-workgroup decoder is the shorter chain: 64 agents 579 vs 616 us per collision-guided step)
                 // the guidance kernel's own forward sweep as the decoder (8 agents per workgroup: the whole chip at 2,048 agents), then
-                // the O(T) roll-out; the actions wait in the gradient buffer the loss kernels fill afterwards
+                // the O(T) roll-out.  Up to 2,048 agents every agent group has a workgroup and a scratch slot of its own in that launch: the
+                // guidance kernel behind the loss kernels then runs its BACKWARD half only (GuideArgs::act_in), from the activations the
+                // forward launch kept -- the sweep is not repeated (a collision-guided step 711 -> 6xx us at 2,048 agents)
                 GuideArgs gf{};
-                gf.mean = g.mean; gf.cond = cond; gf.curr_states = gd->curr_states; gf.scratch = w.guide; gf.B = B; gf.act_out = w.col_grad;
+                gf.mean = g.mean; gf.cond = cond; gf.curr_states = gd->curr_states; gf.scratch = w.guide; gf.B = B; gf.act_out = w.col_act;
                 HIPCK(h, launch_guide_forward(h->dec, h->dyn, gf, s));
-                HIPCK(h, launch_action_to_state(h->dyn, w.col_grad, gd->curr_states, w.col_traj, B, 1, 1, s));
+                HIPCK(h, launch_action_to_state(h->dyn, w.col_act, gd->curr_states, w.col_traj, B, 1, 1, s));
+                g.act_in = guide_split_available(B, h->force_kernel[CLD_KERNEL_GUIDE]) && h->force_kernel[CLD_KERNEL_GUIDE] == FORM_AUTO ? w.col_act : nullptr;
             } else {
                 HIPCK(h, launch_decode(h->dec, h->dyn, g.mean, cond, gd->curr_states, nullptr, w.col_traj, B, 1, s, h->force_kernel[CLD_KERNEL_DECODE]));
             }

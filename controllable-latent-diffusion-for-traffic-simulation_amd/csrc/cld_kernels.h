@@ -300,6 +300,8 @@ struct GuideArgs {
     float* x_out2;              // second copy (the unconditional half in CFG mode) or null
     float* grad_out;            // dL/dmean [B,52,4] or null (diagnostic / tests)
     float* act_out;             // launch_guide_forward only: scaled decoder actions [B,52,2]; the kernel stops behind its forward sweep
+    const float* act_in;        // launch_guide with guide_split_available(): the actions a launch_guide_forward of the SAME mean, scratch and B wrote --
+                                // the kernel then runs its backward half only, from the activations that launch kept in `scratch`
     float* scratch;             // guide_scratch_floats(B) floats
     float lr, perturb_th, sigma;
     int optimizer;              // 0 = Adam, 1 = SGD
@@ -317,6 +319,7 @@ size_t guide_scratch_floats(int B);
 void read_guide_stamps(unsigned long long* out);     // -DCLD_STAMPS builds: 8 shader-clock stamps per workgroup (256 workgroups); else a no-op
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form = FORM_AUTO);
 bool guide_forward_available(int B, int form = FORM_AUTO);
+bool guide_split_available(int B, int form = FORM_AUTO);      // ... and every agent group has a workgroup (and a scratch slot) of its own: forward and backward may be two launches
 hipError_t launch_guide_forward(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s);
 
 // per-agent values of the built-in guidance losses on a decoded trajectory (include/cld.h cld_guidance_losses); uses the loss

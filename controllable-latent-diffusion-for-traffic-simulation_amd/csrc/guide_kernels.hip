@@ -1236,6 +1236,11 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
         for (int i = tid; i < AG * 256; i += 512) condm[i >> 8][i & 255] = a.cond[(size_t)agent(i >> 8) * 256 + (i & 255)];
         for (int i = tid; i < AG * 208; i += 512) zin[i / 208][i % 208] = a.mean[(size_t)agent(i / 208) * 208 + i % 208];
         __syncthreads();
+        // a.act_in: the BACKWARD half of a split call -- the forward sweep of this very group ran in an earlier launch (launch_guide_forward:
+        // same grid, same scratch slot, same mean), its kept activations are in the scratch and its actions in act_in: nothing of the
+        // forward pass is repeated
+        const bool backward_only = a.act_in != nullptr;
+        if (!backward_only) {
         if (wv8 < 4) {   // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49): wave wv8 takes the K quarter 64 wv8 .. + 63 of all 64 units
             const float* wr = w.w_c2h + (size_t)(4 * ul + q) * 256 + 64 * wv8;
             asm volatile("" : "+v"(wr));
@@ -1359,6 +1364,12 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
         for (int i = tid; i < 2 * GT * AG; i += 512) {
             const int o = i / (GT * AG), t = (i / AG) % GT, ag = i % AG;
             act[o][t][ag] = (o ? bh2b : bh2a) + actp[t][o][0][ag] + actp[t][o][1][ag] + actp[t][o][2][ag] + actp[t][o][3][ag];
+        }
+        } else {
+            for (int i = tid; i < 2 * GT * AG; i += 512) {
+                const int ag = i / (2 * GT), t = (i >> 1) % GT, o = i & 1;
+                act[o][t][ag] = a.act_in[((size_t)agent(ag) * GT + t) * 2 + o];
+            }
         }
         __syncthreads();
         if (a.act_out) {       // forward only: the decoder's scaled actions of this group (the caller rolls them out); see launch_guide_forward
@@ -1528,13 +1539,15 @@ size_t guide_scratch_floats(int B) {
 // workgroup) fills half the chip.  Used for the plans the scene-coupled guidance losses are evaluated on (cld_api.hip
 // run_guidance), where a decode precedes every guidance-kernel launch.  False: this batch size does not take the 8-agent form.
 bool guide_forward_available(int B, int form) { return guide_form(B, form) == FORM_MFMA_QUAD; }
+bool guide_split_available(int B, int form) { return guide_form(B, form) == FORM_MFMA_QUAD && (B + gq::AG - 1) / gq::AG <= guide_quad_grid(B); }
 hipError_t launch_guide_forward(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s) {
-    if (!a.act_out) return hipErrorInvalidValue;
+    if (!a.act_out || a.act_in) return hipErrorInvalidValue;
     hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(512), 0, s, w, d, a);
     return hipGetLastError();
 }
 
 hipError_t launch_guide(const DecoderWeights& w, const DynParams& d, const GuideArgs& a, hipStream_t s, int form) {
+    if (a.act_in && !guide_split_available(a.B, form)) return hipErrorInvalidValue;
     switch (guide_form(a.B, form)) {
         case FORM_MFMA_QUAD: hipLaunchKernelGGL(guide_quad_kernel, dim3(guide_quad_grid(a.B)), dim3(512), 0, s, w, d, a); break;
         case FORM_MFMA: hipLaunchKernelGGL(guide_mfma8_kernel, dim3(guide_mfma_grid(a.B)), dim3(512), 0, s, w, d, a); break;
