@@ -136,7 +136,8 @@ template <int L, int CIN, int CS, int COUT, int NM>
 __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, const int cb, const int b0, float* lds1) {
     typedef W1Geo<L, CIN, CS, COUT> G;
     constexpr int ROWS = G::ROWS * NM / 4;             // live rows of the item (at L = 26 the rest of its last M-tile idles)
-    float* xch = lds1 + 2 * G::VBUF;                   // GroupNorm sums meet here: two waves of a 32-channel group; the rows of an agent at L = 26
+    constexpr int VB = 8 * 16 * NM * G::KC;             // floats per V image of this item: 8 xi x 16 NM rows x 16 channels (a half item's images are half as large)
+    float* xch = lds1 + 2 * VB;                        // GroupNorm sums meet here: two waves of a 32-channel group; the rows of an agent at L = 26
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     W1STAMP(0);
@@ -185,8 +186,8 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
     };
     // B^T d in four pieces (xi pairs share their even / odd halves), each stored as it is formed
     auto transform_piece = [&](const int k, const int buf) {
-        float* vb = lds1 + buf * G::VBUF + wofs;
-        auto st = [&](const int xi, const vS v) { *reinterpret_cast<vS*>(vb + xi * (64 * 16)) = v; };
+        float* vb = lds1 + buf * VB + wofs;
+        auto st = [&](const int xi, const vS v) { *reinterpret_cast<vS*>(vb + xi * (16 * NM * 16)) = v; };
         if (k == 0) {
             const vS e = fmaS(d[4], -4.25f, d[2] + d[6]), o = fmaS(d[3], -4.25f, d[1] + d[5]);
             st(1, e + o); st(2, e - o);
@@ -234,8 +235,8 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
     // one chunk: 8 xi x NM M-tiles x 4 MFMAs.  Fragments run two (xi, M-tile) items ahead of their MFMAs (a rolling window of three);
     // the next chunk's rows are requested during xi = 0, 1 and transformed during xi = 4 .. 7
     auto mfma_block = [&](const int buf, const int c, const bool stage) {
-        const int bo = buf * (G::VBUF * 4);
-        auto frag = [&](const int it) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + (it / NM) * 4096 + (it % NM) * 1024); };
+        const int bo = buf * (VB * 4);
+        auto frag = [&](const int it) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + it * 1024); };      // (xi, M-tile) = it / NM, it % NM: images of 16 NM rows
         v4f ar[3];
         ar[0] = frag(0);
         ar[1] = frag(1);
@@ -428,10 +429,16 @@ __device__ __forceinline__ void wino1d_item(const ConvArgs& p, const int b_pad, 
 // below that every group is split into two half items (two M-tiles each: twice the U traffic per MFMA, but a second wave on every SIMD:
 // at 1,024 rows 256 whole items leave every CU with one workgroup).  ids x, x + 8, x + 16, x + 24 (whole) resp. 2 x the same (halves) are
 // the channel blocks of one agent group: one XCD, back to back.
-template <int L, int CIN, int CS, int COUT>
-__global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map, const int halves) {
+// Two instantiations per layer shape: whole items (128 accumulator registers: two workgroups per CU) and half items, which need half the
+// accumulators and half the LDS (36 KB) -- WINO1D_HALF_WGS workgroups per CU.
+#ifndef WINO1D_HALF_WGS
+#define WINO1D_HALF_WGS 2
+#endif
+template <int L, int CIN, int CS, int COUT, int HALVES>
+__global__ __launch_bounds__(256, HALVES ? WINO1D_HALF_WGS : 2) void wino1d_conv_kernel(const ConvArgs p, const int b_pad, const int xcd_map) {
     typedef W1Geo<L, CIN, CS, COUT> G;
     extern __shared__ __attribute__((aligned(16))) float lds1[];
+    constexpr int halves = HALVES;
     const int e = halves ? blockIdx.x >> 1 : blockIdx.x, half = halves ? (int)(blockIdx.x & 1) : -1;
     int cb, grp;
     if (xcd_map) {
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_conv_kernel(const ConvArgs p, c
         cb = e % G::NCB;
         grp = e / G::NCB;
     }
-    if (half < 0) wino1d_item<L, CIN, CS, COUT, 4>(p, b_pad, cb, grp * G::AG, lds1);
+    if constexpr (!HALVES) wino1d_item<L, CIN, CS, COUT, 4>(p, b_pad, cb, grp * G::AG, lds1);
     else wino1d_item<L, CIN, CS, COUT, 2>(p, b_pad, cb, grp * G::AG + half * (G::AG / 2), lds1);
 }
 
@@ -468,16 +475,20 @@ long wino1d_gemm_rows(int l_in, int b_pad) { return l_in == 13 ? 4L * b_pad : 8L
 template <int L, int CIN, int CS, int COUT>
 static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     typedef W1Geo<L, CIN, CS, COUT> G;
-    auto kern = wino1d_conv_kernel<L, CIN, CS, COUT>;
-    static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
-    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
+    auto kern_whole = wino1d_conv_kernel<L, CIN, CS, COUT, 0>;
+    auto kern_half = wino1d_conv_kernel<L, CIN, CS, COUT, 1>;
+    constexpr size_t lds_half = (2 * (G::VBUF / 2) + G::XCH) * sizeof(float);
+    static unsigned long long attr_done = 0, attr_done_h = 0;      // one bit per device (a second handle on another device sets it there too)
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern_whole), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern_half), (int)lds_half, &attr_done_h); e != hipSuccess) return e;
     if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
     const int groups = b_pad / G::AG, nfull = groups * G::NCB;
     // whole items when they fill generations of 512 (two workgroups per CU); halves below one generation and when the last generation
     // would be at most half full (752 whole items are two rounds, 1,504 halves one and a half)
     const int tail = nfull % WINO1D_HALVES_BELOW;
     const int halves = (nfull < WINO1D_HALVES_BELOW || (tail != 0 && tail <= WINO1D_HALVES_BELOW / 2)) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3(nfull << halves), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0, halves);
+    if (halves) hipLaunchKernelGGL(kern_half, dim3(nfull << 1), dim3(256), lds_half, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
+    else hipLaunchKernelGGL(kern_whole, dim3(nfull), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
     return hipGetLastError();
 }
 
