@@ -282,7 +282,7 @@ def main():
                         "frac": round(ex_ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],
                         "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                        else "v_mfma_f32_16x16x4_f32 dense peak"),
-                        "kernel": ("wino1d_conv_kernel<13,256,256,256> (%s)" % what if wino else
+                        "kernel": ("wino1d_conv_kernel<13,256,256,256,0> (%s)" % what if wino else
                                    "conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0,0> (%s; tiling picked by the rows per launch)"
                                    % ("4,1" if rows >= 2048 else ("4,2" if rows >= 1024 else "2,2"), what)),
                         "agents_per_launch": rows, "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),
