@@ -1741,8 +1741,12 @@ int cld_context_encode(cld_handle h, const float* image, const float* curr_state
     const int pass = wino ? context_pass_size(B) : cb;
     for (int b0 = 0; b0 < B; b0 += pass) {
         const int n = (B - b0) < pass ? (B - b0) : pass;
-        HIPCK(h, launch_stem_conv(image + (size_t)b0 * 34 * 224 * 224, h->stem_w, h->stem_scale, h->stem_shift, y1, n, s));
-        HIPCK(h, launch_maxpool(y1, buf[0], n, s));
+        if (h->force_kernel[CLD_KERNEL_CONTEXT] == CLD_FORM_DIRECT) {      // the direct form of the encoder: stem and max-pool as two launches
+            HIPCK(h, launch_stem_conv(image + (size_t)b0 * 34 * 224 * 224, h->stem_w, h->stem_scale, h->stem_shift, y1, nullptr, n, s));
+            HIPCK(h, launch_maxpool(y1, buf[0], n, s));
+        } else {                                                          // max-pool inside the stem's epilogue: [n,112,112,64] is never written
+            HIPCK(h, launch_stem_conv(image + (size_t)b0 * 34 * 224 * 224, h->stem_w, h->stem_scale, h->stem_shift, nullptr, buf[0], n, s));
+        }
         int xi = 0;                                            // buffer holding the current block input
         for (int li = 0; li < 4; ++li)
             for (int b = 0; b < 2; ++b) {                      // BasicBlock: relu(bn2(conv2(relu(bn1(conv1 x)))) + identity)

@@ -246,7 +246,8 @@ hipError_t launch_world_step(const float* traj, const float* centroid, const flo
 
 // ---- ContextEncoder (models/context_utils.py:8-61; context_kernels.hip) ------------------------------------
 // stem: image [B,34,224,224] NCHW -> y [B,112,112,64] NHWC = ReLU(BN(conv 7x7/2)); wq: packed by pack_stem_weights
-hipError_t launch_stem_conv(const float* image, const float* wq, const float* scale, const float* shift, float* y, int B,
+// pooled != null: MaxPool2d(3, 2, 1) fused (y unused): pooled [B,56,56,64] NHWC, zero-filled by the launcher, completed by atomic max
+hipError_t launch_stem_conv(const float* image, const float* wq, const float* scale, const float* shift, float* y, float* pooled, int B,
                             hipStream_t s);
 // MaxPool2d(3, 2, 1): [B,112,112,64] -> [B,56,56,64] (NHWC)
 hipError_t launch_maxpool(const float* x, float* y, int B, hipStream_t s);

@@ -49,9 +49,14 @@ constexpr int BUF = PRW * RS;             // floats per strip image
 // of k-steps 4qg..4qg+3; scale/shift [64]: folded BatchNorm; y [B,112,112,64] NHWC.
 // three workgroups per CU (<= 168 VGPRs: the plane batch is 2 deep for that) so that one workgroup's plane loads and
 // barriers hide behind the MFMAs of the others: 1.44 -> 1.25 ms structured, 6.59 -> 6.42 ms dense per 256 agents
+// pooled != null: MaxPool2d(3, stride 2, pad 1) (base_models.py:559-614: resnet18's maxpool) is applied here instead of by a launch of its
+// own -- y is not written at all.  Pooled pixel (pr, pc) is the maximum over conv rows 2 pr - 1 .. 2 pr + 1 and columns 2 pc - 1 .. 2 pc + 1.
+// A workgroup owns conv rows 2 k and 2 k + 1, a lane four consecutive columns c0 .. c0 + 3 (c0 a multiple of 4) of one channel: it takes
+// the maxima it can form in registers and hands them to the pooled tensor with atomic max -- exact and order-independent; the values are
+// ReLU outputs (>= 0), so their bit patterns compare like unsigned integers and the caller's zero fill is the identity.
 __global__ __launch_bounds__(256, stem::TR == 2 ? 3 : 2) void stem_conv_kernel(const float* __restrict__ image, const float* __restrict__ wq,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       float* __restrict__ y, int B) {
+                                                       float* __restrict__ y, float* __restrict__ pooled, int B) {
     using namespace stem;
     __shared__ float lds[2 * BUF];
     __shared__ int plane_nz[CIN];                   // 7-bit mask per input plane: which 16-column output blocks of this strip see a non-zero value
@@ -229,6 +234,32 @@ __global__ __launch_bounds__(256, stem::TR == 2 ? 3 : 2) void stem_conv_kernel(c
     // epilogue: folded BatchNorm + ReLU; lane holds rows 4 (lane >> 4) + r of column n = 16 wave + i16 of every M-tile
     const int n = 16 * wave + i16;
     const float sc = scale[n], sh = shift[n];
+    if (pooled) {
+        static_assert(TR == 2 || TR == 4, "the fused pool pairs conv rows 2 k, 2 k + 1");
+        unsigned* pl = reinterpret_cast<unsigned*>(pooled) + (size_t)b * 56 * 56 * COUT + n;
+        auto amax = [&](const int pr, const int pc, const float v) {
+            if (pr < 56 && pc < 56) atomicMax(pl + ((size_t)pr * 56 + pc) * COUT, __builtin_bit_cast(unsigned, v));
+        };
+#pragma unroll
+        for (int rp = 0; rp < TR / 2; ++rp)                  // row pairs (2 k, 2 k + 1) of this workgroup
+#pragma unroll
+            for (int mc = 0; mc < 7; ++mc) {
+                const int k = r0 / 2 + rp, c0 = 16 * mc + 4 * kk;
+                float e[4], o[4];                            // even row 2 k, odd row 2 k + 1
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = fmaxf(acc[mc + 7 * (2 * rp)][r] * sc + sh, 0.f);
+                    o[r] = fmaxf(acc[mc + 7 * (2 * rp + 1)][r] * sc + sh, 0.f);
+                }
+                // horizontal pieces: pooled column c0 / 2 sees columns c0, c0 + 1 of this lane (and c0 - 1 of its neighbour), c0 / 2 + 1 sees
+                // c0 + 1 .. c0 + 3, c0 / 2 + 2 sees c0 + 3
+                const float oa = fmaxf(o[0], o[1]), ob = fmaxf(fmaxf(o[1], o[2]), o[3]), oc = o[3];
+                const float va = fmaxf(fmaxf(e[0], e[1]), oa), vb = fmaxf(fmaxf(fmaxf(e[1], e[2]), e[3]), ob), vc = fmaxf(e[3], oc);
+                amax(k, c0 / 2, va); amax(k, c0 / 2 + 1, vb); amax(k, c0 / 2 + 2, vc);                  // pooled row k: rows 2 k, 2 k + 1
+                amax(k + 1, c0 / 2, oa); amax(k + 1, c0 / 2 + 1, ob); amax(k + 1, c0 / 2 + 2, oc);      // pooled row k + 1: row 2 k + 1 is its row above
+            }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < SMT; ++m) {
         const int orow = r0 + m / 7;
@@ -241,9 +272,13 @@ __global__ __launch_bounds__(256, stem::TR == 2 ? 3 : 2) void stem_conv_kernel(c
     }
 }
 
-hipError_t launch_stem_conv(const float* image, const float* wq, const float* scale, const float* shift, float* y, int B,
+hipError_t launch_stem_conv(const float* image, const float* wq, const float* scale, const float* shift, float* y, float* pooled, int B,
                             hipStream_t s) {
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((stem::HO / stem::TR) * B), dim3(256), 0, s, image, wq, scale, shift, y, B);
+    if (pooled) {      // the fused max-pool accumulates by atomic max: the pooled tensor starts at 0 (= the smallest ReLU output)
+        hipError_t e = hipMemsetAsync(pooled, 0, (size_t)B * 56 * 56 * stem::COUT * sizeof(float), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((stem::HO / stem::TR) * B), dim3(256), 0, s, image, wq, scale, shift, y, pooled, B);
     return hipGetLastError();
 }
 
@@ -558,7 +593,23 @@ __device__ __forceinline__ void linear_4(const float* in /*LDS [4][stride]*/, in
         const bool ok = j < n_out;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (ok) {
-            for (int i = 0; i < n_in; ++i) {
+            // the kernel is ONE workgroup's chain of nine such products (63 workgroups at 250 agents: a single generation), and a product is
+            // n_in dependent steps of (weight from L2, four FMAs): sixteen weights are requested at a time so that a step does not wait out a
+            // trip to L2 each (same order of additions: results unchanged)
+            int i = 0;
+            for (; i + 16 <= n_in; i += 16) {
+                float w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = wt[(size_t)(i + u) * n_out + j];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    a0 = fmaf(in[i + u], w[u], a0);
+                    a1 = fmaf(in[stride + i + u], w[u], a1);
+                    a2 = fmaf(in[2 * stride + i + u], w[u], a2);
+                    a3 = fmaf(in[3 * stride + i + u], w[u], a3);
+                }
+            }
+            for (; i < n_in; ++i) {
                 const float w = wt[(size_t)i * n_out + j];
                 a0 = fmaf(in[i], w, a0);
                 a1 = fmaf(in[stride + i], w, a1);
@@ -601,8 +652,13 @@ __global__ __launch_bounds__(256) void context_head_kernel(const ContextHeadArgs
             for (int k = 0; k < 2; ++k) {
                 const int ch = tid + 256 * k;
                 float s = 0.f;
-                if (b < a.B)
-                    for (int px = 0; px < 49; ++px) s += a.feat[((size_t)b * 49 + px) * 512 + ch];
+                if (b < a.B) {
+                    float fv[49];                   // (all 49 requested before the first add: same order of additions)
+#pragma unroll
+                    for (int px = 0; px < 49; ++px) fv[px] = a.feat[((size_t)b * 49 + px) * 512 + ch];
+#pragma unroll
+                    for (int px = 0; px < 49; ++px) s += fv[px];
+                }
                 pooled[g][ch] = s * (1.0f / 49.0f);
             }
         }

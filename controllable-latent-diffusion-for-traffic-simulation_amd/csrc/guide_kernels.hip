@@ -1240,6 +1240,8 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
         // same grid, same scratch slot, same mean), its kept activations are in the scratch and its actions in act_in: nothing of the
         // forward pass is repeated
         const bool backward_only = a.act_in != nullptr;
+        float c0 = 0.f, c1 = 0.f;
+        GPHASE_DECL;
         if (!backward_only) {
         if (wv8 < 4) {   // h0 = cond2hidden(cond) for both layers (lstm_vae.py:46-49): wave wv8 takes the K quarter 64 wv8 .. + 63 of all 64 units
             const float* wr = w.w_c2h + (size_t)(4 * ul + q) * 256 + 64 * wv8;
@@ -1269,8 +1271,6 @@ __global__ __launch_bounds__(512) void guide_quad_kernel(const DecoderWeights w,
             hs[0][0][ag][uu] = v;
             hs[1][0][ag][uu] = v;
         }
-        float c0 = 0.f, c1 = 0.f;
-        GPHASE_DECL;
         __syncthreads();
         GSTAMP(1);
         // ---------------- forward ----------------
