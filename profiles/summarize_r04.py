@@ -65,9 +65,11 @@ fe, wr = avg("stem_conv_kernel", "FETCH_SIZE"), avg("stem_conv_kernel", "WRITE_S
 if fe is not None and wr is not None:
     json.dump({"kernel": "cld::stem_conv_kernel", "agents_per_launch": 256,
                "hbm_bytes_per_launch": int(2 * fe * 1024 + wr * 1024), "fetch_bytes_x2_corrected": int(2 * fe * 1024), "write_bytes": int(wr * 1024),
-               "algorithmic_bytes_per_launch": {"raster_in": 256 * 34 * 224 * 224 * 4, "weights": 557056, "output": 256 * 112 * 112 * 64 * 4},
+               "algorithmic_bytes_per_launch": {"raster_in": 256 * 34 * 224 * 224 * 4, "weights": 557056, "pooled_output": 256 * 56 * 56 * 64 * 4},
                "note": "average over the dense and the structured raster passes of scripts/ctx_time.py 256; the 9-row strips of "
-                       "neighbouring workgroups overlap (2.25x re-read of the raster, served by L2 / Infinity Cache)"},
+                       "neighbouring workgroups overlap (2.25x re-read of the raster, served by L2 / Infinity Cache); round 4: the max-pool is "
+                       "fused -- the kernel writes the pooled [n,56,56,64] tensor by atomic max (counted as write traffic; up to six updates "
+                       "per pooled value) instead of the [n,112,112,64] conv output (822 MB), and the separate max-pool launch is gone"},
               open(os.path.join(DST, "traffic_stem.json"), "w"), indent=1)
 chains = {}
 # (round 4: the chains in Winograd form; weights = three / four k5 layers' G g at 131,072 B + the direct-form layers; kept slots 4,096 / 2,048 floats per agent)
@@ -87,3 +89,17 @@ if chains:
     print(json.dumps(chains, indent=1))
 print(open(os.path.join(DST, "traffic.json")).read() if out else "no traffic")
 print(open(os.path.join(DST, "traffic_stem.json")).read())
+
+# MFMA-busy share per kernel of the headline bench: SQ_VALU_MFMA_BUSY_CYCLES per launch / (1,024 SIMDs x average duration x 2.4 GHz)
+ks = {r["Name"].split("(")[0]: float(r["AverageNs"]) for r in csv.DictReader(open(os.path.join(DST, "kernel_stats_bench_configs2_steps1_warmup1.csv")))}
+with open(os.path.join(DST, "mfma_busy.txt"), "w") as f:
+    f.write("MFMA pipe busy share per kernel of `bench.py --steps 1 --warmup 1` (configs[2], 4,096 rows per launch set): SQ_VALU_MFMA_BUSY_CYCLES per launch\n"
+            "(pmc_per_launch_avg.csv) / (1,024 SIMDs x average kernel-trace duration x 2.4 GHz); the chip holds ~2.1-2.2 GHz under this load, so the share of the\n"
+            "cycles it really ran is ~10 % higher\n")
+    for (k, c), (sv, n) in sorted(rows.items()):
+        if c != "SQ_VALU_MFMA_BUSY_CYCLES":
+            continue
+        d = ks.get(k.split("(")[0])
+        if d and any(t in k for t in ("wino1d", "chain", "guide", "conv_block", "conv_pair")):
+            f.write(f"{k.split('(')[0][10:]:60s} {d / 1e3:8.1f} us  {sv / n / 1024 / (d * 1e-9 * 2.4e9) * 100:5.1f} %\n")
+print(open(os.path.join(DST, "mfma_busy.txt")).read())
