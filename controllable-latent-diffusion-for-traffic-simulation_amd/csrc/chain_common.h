@@ -60,15 +60,15 @@ struct Geo {
     static constexpr int C = 64, L = L_, AG = AG_;
     static constexpr int KCP = C + 8;
     static constexpr int LP = L + 2;
-    static constexpr int AEX = (AG == 4 && L == 26) ? 16 : 0;
+    static constexpr int AEX = (AG == 4 && L == 26) ? 16 : (AG == 2 && L == 52) ? 8 : 0;      // (AG = 2, chain_wino.hip: the L = 52 image is read with stride 2)
     static constexpr int ASTR = LP * KCP + AEX;
     static constexpr int RPT = 16 / AG;                 // rows of one agent per M-tile
     static constexpr int NMT = (AG * L + 15) / 16;
     static constexpr bool RAGGED = NMT * 16 != AG * L;  // the last M-tile carries rows past the agents' ends
     static constexpr int IMG = (AG * LP + 2) * KCP + AG * AEX;
-    static_assert(AG == 4 || AG == 1, "tiles of 4 agents or of 1");
-    static __device__ __forceinline__ int agent(int q, int r) { return AG == 4 ? r : 0; }
-    static __device__ __forceinline__ int pos(int m, int q, int r) { return AG == 4 ? 4 * m + q : 16 * m + 4 * q + r; }
+    static_assert(AG == 4 || AG == 2 || AG == 1, "tiles of 4 agents, of 2 (chain_wino.hip only) or of 1");
+    static __device__ __forceinline__ int agent(int q, int r) { return AG == 4 ? r : AG == 2 ? (r & 1) : 0; }
+    static __device__ __forceinline__ int pos(int m, int q, int r) { return AG == 4 ? 4 * m + q : AG == 2 ? 8 * m + 2 * q + (r >> 1) : 16 * m + 4 * q + r; }
     static __device__ __forceinline__ bool ok(int m, int q, int r) { return !RAGGED || m < NMT - 1 || pos(m, q, r) < L; }
     // float offset of (agent, row) of accumulator register r of M-tile m relative to the lane's base  row0(q) * KCP
     static constexpr int roff(int m, int r) { return AG == 4 ? r * ASTR + 4 * m * KCP : (16 * m + r) * KCP; }

@@ -69,16 +69,20 @@ __device__ __forceinline__ float swap16_sum(const float s) {      // s + the val
 
 // Geometry of the (agent, tile) layout of a four-agent tile at L rows: GEMM row = TPA agent + tile; lane (i16, kk) of wave w, M-tile m:
 // row 16 m + i16, channels 16 w + 4 kk .. + 3, the four outputs 4 tile + o.
-template <int L_>
+// Tiles of AG agents: 4 (64 KB of V resident, two workgroups per CU: the form of rounds 4's first measurements), 2 or 1 (32 KB of V, <= 170
+// registers: three workgroups per CU -- a chain wave spends about a third of its life issuing MFMAs, so a third wave per SIMD fills more of the
+// pipe than the doubled / quadrupled U traffic per MFMA costs; AG = 1 is also the small-batch tile).
+template <int L_, int AG_ = 4>
 struct WGeo {
-    static constexpr int L = L_, TPA = (L + 3) / 4, ROWS = 4 * TPA, NM = (ROWS + 15) / 16, R = 16 * NM;
-    static constexpr bool TWO_PHASE = NM == 4;            // L = 52: V of four xi resident at a time
-    static constexpr int NS = TWO_PHASE ? 4 : 8;          // xi images resident at once
+    static constexpr int L = L_, AG = AG_, TPA = (L + 3) / 4, ROWS = AG * TPA, NM = (ROWS + 15) / 16, R = 16 * NM;
     static constexpr int XIB = R * 256;                   // bytes of one xi image: R rows x 64 channels
-    static constexpr int WD = NM == 4 ? 5 : 10;           // U fragments in flight: an item is 4 NM MFMAs = 128 NM cycles, a fragment comes from L2
-    static_assert(NS * XIB == 65536, "64 KB of V resident");
+    static constexpr int VBYTES = AG == 4 ? 65536 : 32768;
+    static constexpr bool TWO_PHASE = 8 * XIB > VBYTES;   // V of four xi resident at a time
+    static constexpr int NS = TWO_PHASE ? 4 : 8;          // xi images resident at once
+    static constexpr int WD = NM == 4 ? 5 : NM == 2 ? 10 : 12;      // U fragments in flight: an item is 4 NM MFMAs = 128 NM cycles, a fragment comes from L2
+    static_assert(NS * XIB <= VBYTES, "V fits its region");
 };
-constexpr int kVFloats = 16384;                           // the V region
+template <int AG> constexpr int v_floats() { return AG == 4 ? 16384 : 8192; }      // the V region
 constexpr int kGnFloats = 1024;                           // GroupNorm row sums behind it: [pass 2][wave 4][group of the wave 2][row 64]
 // transform point of image slot s of phase PH (0 | 1: the halves of a two-phase layer; 2: all eight)
 __device__ __forceinline__ constexpr int xi_of(int ph, int s) {
@@ -316,18 +320,19 @@ __device__ __forceinline__ void to_image_rows(const v4f (&Y)[W::NM][4], const Ro
 // ---------------------------------------------------------------------------------------------------------------------
 // downs.0 as one launch, k5 layers in Winograd form
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHeadArgs p) {
-    typedef WGeo<52> W;
-    typedef Geo<52, 4> G;
-    typedef Geo<26, 4> GO;
+template <int AG>
+__global__ __launch_bounds__(256, AG == 4 ? 2 : 3) void chain_head_wino_kernel(const ChainHeadArgs p) {
+    typedef WGeo<52, AG> W;
+    typedef Geo<52, AG> G;
+    typedef Geo<26, AG> GO;
     constexpr int NM = W::NM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* gn = lds + kVFloats;
-    float* xl = lds + kVFloats + kGnFloats;              // latent rows [4 agents][2 + 52 + 2][4], the halo rows zero
+    float* gn = lds + v_floats<AG>();
+    float* xl = lds + v_floats<AG>() + kGnFloats;        // latent rows [AG agents][2 + 52 + 2][4], the halo rows zero
     char* ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = blockIdx.x * 4;
+    const int b0 = blockIdx.x * AG;
     const int n4 = 16 * wave + 4 * kk;                   // this lane's four output channels
     Rows<W> rw;
     rw.init(i16);
@@ -348,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
     const int wvoff = lane * 16, wsoff = wave * 1024;
 
     v4f uq[W::WD];
-    uprime<W, 0>(uq, p.st[1].ufrag, wvoff, wsoff);
+    uprime<W, W::TWO_PHASE ? 0 : 2>(uq, p.st[1].ufrag, wvoff, wsoff);      // (the first phase of the layer form this tile takes)
 
     // ---- latent rows -> xl ----
-    if (tid < 4 * 56) {
+    if (tid < AG * 56) {
         const int a = tid / 56, l = tid % 56 - 2;
         v4f v = {0.f, 0.f, 0.f, 0.f};
         if (l >= 0 && l < 52) v = *reinterpret_cast<const v4f*>(p.x + ((size_t)(b0 + a) * 52 + l) * 4);
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
         CSTAMP(2 * s);
         out_transform<NM>(acc, *reinterpret_cast<const v4f*>(st.bias + n4), Y);
         // the next layer's first weight fragments travel under this layer's epilogue
-        if (s < 3) uprime<W, 0>(uq, p.st[s + 1].ufrag, wvoff, wsoff);
+        if (s < 3) uprime<W, W::TWO_PHASE ? 0 : 2>(uq, p.st[s + 1].ufrag, wvoff, wsoff);
         load_add(st.cb_off);
         gn_mish_rows<W>(Y, rw, *reinterpret_cast<const v4f*>(st.gamma + n4), *reinterpret_cast<const v4f*>(st.beta + n4), add, gnw, i16, kk);
         if (st.res_kind == CHAIN_RES_LATENT) {
@@ -456,11 +461,11 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
         v4f acd[GO::NMT];
 #pragma unroll
         for (int m = 0; m < GO::NMT; ++m) acd[m] = v4f{0.f, 0.f, 0.f, 0.f};
-        kloop<G::KCP, 2 * MSTEP, 64, 3, GO::NMT>(acd, ldsb, ((n16 % 4) * G::ASTR + (1 + 2 * (n16 / 4)) * G::KCP + 4 * q) * 4, rsw, lane * 16, 4, wave, wqd);
+        kloop<G::KCP, 2 * MSTEP, 64, 3, GO::NMT>(acd, ldsb, ((n16 % AG) * G::ASTR + (1 + 2 * (n16 / AG)) * G::KCP + 4 * q) * 4, rsw, lane * 16, 4, wave, wqd);
         CSTAMP(8);
         const float bias = st.bias[n];
         const size_t ybase = (size_t)b0 * 26 * 64;
-        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y + ybase, 0, 4 * 26 * 64 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y + ybase, 0, AG * 26 * 64 * 4, 0x00020000);
 #pragma unroll
         for (int m = 0; m < GO::NMT; ++m)
 #pragma unroll
@@ -473,36 +478,46 @@ __global__ __launch_bounds__(256, 2) void chain_head_wino_kernel(const ChainHead
     CSTAMP_RT(15);
 }
 
-constexpr size_t kHeadWinoLds = sizeof(float) * (kVFloats + kGnFloats + 4 * 56 * 4);
-static_assert(sizeof(float) * img_floats<4>() <= sizeof(float) * (kVFloats + kGnFloats), "the stride-2 conv's image fits in front of the latent rows");
-static_assert(2 * kHeadWinoLds <= 160 * 1024, "two workgroups per CU");
+template <int AG> constexpr size_t head_wino_lds() { return sizeof(float) * (v_floats<AG>() + kGnFloats + AG * 56 * 4); }
+static_assert(img_floats<4>() <= v_floats<4>() + kGnFloats && img_floats<2>() <= v_floats<2>() + kGnFloats && img_floats<1>() <= v_floats<1>() + kGnFloats,
+              "the stride-2 conv's image fits in front of the latent rows");
+static_assert(2 * head_wino_lds<4>() <= 160 * 1024 && 3 * head_wino_lds<2>() <= 160 * 1024, "two / three workgroups per CU");
 
-hipError_t launch_chain_head_wino(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
+template <int AG>
+static hipError_t launch_chain_head_wino_inst(const ChainHeadArgs& a, int b_pad, hipStream_t s) {
     static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
-    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_head_wino_kernel), 160 * 1024, &attr_done); e != hipSuccess) return e;
-    if (b_pad % 4) return hipErrorInvalidValue;
-    for (int i = 1; i <= 3; ++i)
-        if (!a.st[i].ufrag) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chain_head_wino_kernel, dim3(b_pad / 4), dim3(256), kHeadWinoLds, s, a);
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_head_wino_kernel<AG>), 160 * 1024, &attr_done); e != hipSuccess) return e;
+    if (b_pad % AG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_head_wino_kernel<AG>, dim3(b_pad / AG), dim3(256), head_wino_lds<AG>(), s, a);
     return hipGetLastError();
 }
-// MFMAs per wave and workgroup: the latent's conv (5 x 16), three Winograd layers (8 xi x 4 chunks x 4 M-tiles x 4), the stride-2 conv
-double chain_head_wino_exec_flop(int b_pad) { return (80.0 + 3 * 512.0 + 48.0 * Geo<26, 4>::NMT) * 4 * 2048.0 * (b_pad / 4); }
+hipError_t launch_chain_head_wino(const ChainHeadArgs& a, int b_pad, int agents_per_tile, hipStream_t s) {
+    for (int i = 1; i <= 3; ++i)
+        if (!a.st[i].ufrag) return hipErrorInvalidValue;
+    return agents_per_tile == 4 ? launch_chain_head_wino_inst<4>(a, b_pad, s)
+         : agents_per_tile == 2 ? launch_chain_head_wino_inst<2>(a, b_pad, s) : launch_chain_head_wino_inst<1>(a, b_pad, s);
+}
+// MFMAs per wave and workgroup: the latent's conv (5 per M-tile and output), three Winograd layers (8 xi x 4 chunks x NM M-tiles x 4), the stride-2 conv
+template <int AG> static constexpr double head_wino_mfma() { return 20.0 * WGeo<52, AG>::NM + 3 * 128.0 * WGeo<52, AG>::NM + 48.0 * Geo<26, AG>::NMT; }
+double chain_head_wino_exec_flop(int b_pad, int agents_per_tile) {
+    return (agents_per_tile == 4 ? head_wino_mfma<4>() : agents_per_tile == 2 ? head_wino_mfma<2>() : head_wino_mfma<1>()) * 4 * 2048.0 * (b_pad / agents_per_tile);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_conv as one launch, k5 layers in Winograd form
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTailArgs p) {
-    typedef WGeo<26> W;            // stages 0..2
-    typedef WGeo<52> V;            // the transposed conv's output, final_conv.0
-    typedef Geo<26, 4> G;
-    typedef Geo<52, 4> H;
+template <int AG>
+__global__ __launch_bounds__(256, AG == 4 ? 2 : 3) void chain_tail_wino_kernel(const ChainTailArgs p) {
+    typedef WGeo<26, AG> W;        // stages 0..2
+    typedef WGeo<52, AG> V;        // the transposed conv's output, final_conv.0
+    typedef Geo<26, AG> G;
+    typedef Geo<52, AG> H;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* gn = lds + kVFloats;
+    float* gn = lds + v_floats<AG>();
     char* ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b0 = blockIdx.x * 4;
+    const int b0 = blockIdx.x * AG;
     const int n4 = 16 * wave + 4 * kk;
     Rows<W> rw;
     rw.init(i16);
@@ -518,11 +533,11 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
     v4f Yf[V::NM][4];              // the L = 52 half of the kernel; the L = 26 stages use the first two M-tiles' worth
     {
         v4f uq[W::WD];
-        uprime<W, 2>(uq, p.st[0].ufrag, wvoff, wsoff);
+        uprime<W, W::TWO_PHASE ? 0 : 2>(uq, p.st[0].ufrag, wvoff, wsoff);
         v4f Y[W::NM][4];
         // ---- input rows [4 agents][26][64] -> the (agent, tile) layout: 16 bytes per (row, output) and lane; rows past the agent's end read 0 ----
         {
-            const int xbytes = 4 * 26 * 64 * 4;
+            const int xbytes = AG * 26 * 64 * 4;
             const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)b0 * 26 * 64), 0, xbytes, 0x00020000);
 #pragma unroll
             for (int m = 0; m < W::NM; ++m)
@@ -541,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
             v4f acc[8][W::NM];
             wino_layer<W>(Y, acc, rw, ldsb, aoff, wofs, i16, uq, st.ufrag, wvoff, wsoff);
             out_transform<W::NM>(acc, *reinterpret_cast<const v4f*>(st.bias + n4), Y);
-            if (s < 2) uprime<W, 2>(uq, p.st[s + 1].ufrag, wvoff, wsoff);
+            if (s < 2) uprime<W, W::TWO_PHASE ? 0 : 2>(uq, p.st[s + 1].ufrag, wvoff, wsoff);
             const v4f tb = (p.tbias && st.cb_off >= 0) ? *reinterpret_cast<const v4f*>(p.tbias + st.cb_off + n4) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < W::NM; ++m) {
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
             }
             v4f rres[W::NM][4];                          // residual rows, requested ahead of the GroupNorm passes that cover their latency
             if (st.res_kind == CHAIN_RES_TENSOR) {
-                const int rbytes = 4 * 26 * 64 * 4;      // rows past the agent's end: out of range, read 0
+                const int rbytes = AG * 26 * 64 * 4;     // rows past the agent's end: out of range, read 0
                 const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(st.res + (size_t)b0 * 26 * 64), 0, rbytes, 0x00020000);
 #pragma unroll
                 for (int m = 0; m < W::NM; ++m)
@@ -631,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
     // ---- final_conv.0: Conv1d(64 -> 64, k5) + GroupNorm + Mish at L = 52, Winograd form ----
     {
         v4f uq[V::WD];
-        uprime<V, 0>(uq, p.fin.ufrag, wvoff, wsoff);
+        uprime<V, V::TWO_PHASE ? 0 : 2>(uq, p.fin.ufrag, wvoff, wsoff);
         v4f acc[8][V::NM];
         wino_layer<V>(Yf, acc, rv, ldsb, aoff, wofs, i16, uq, p.fin.ufrag, wvoff, wsoff);
         out_transform<V::NM>(acc, *reinterpret_cast<const v4f*>(p.fin.bias + n4), Yf);
@@ -679,9 +694,9 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
                 if (m >= H::NMT) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int pos = 4 * m + q;
+                    const int pos = H::RPT * m + (4 * q + r) / AG;      // H::pos with a run-time M-tile
                     if (pos >= 52) continue;
-                    const int b = b0 + r;
+                    const int b = b0 + H::agent(q, r);
                     const size_t row = (size_t)b * 52 + pos, e = row * 4 + n16;
                     const float ev = ah[mi][r] + hb;
                     if (p.eps) p.eps[e] = ev;
@@ -700,18 +715,28 @@ __global__ __launch_bounds__(256, 2) void chain_tail_wino_kernel(const ChainTail
     }
 }
 
-constexpr size_t kTailWinoLds = sizeof(float) * (kVFloats + kGnFloats);
-static_assert(sizeof(float) * img_floats<4>() <= kTailWinoLds, "the spatial images fit in the V region");
+template <int AG> constexpr size_t tail_wino_lds() { return sizeof(float) * (v_floats<AG>() + kGnFloats); }
 
-hipError_t launch_chain_tail_wino(const ChainTailArgs& a, int b_pad, hipStream_t s) {
+template <int AG>
+static hipError_t launch_chain_tail_wino_inst(const ChainTailArgs& a, int b_pad, hipStream_t s) {
     static unsigned long long attr_done = 0;      // one bit per device (a second handle on another device sets it there too)
-    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_tail_wino_kernel), 160 * 1024, &attr_done); e != hipSuccess) return e;
-    if (b_pad % 4 || !a.st[0].ufrag || !a.st[1].ufrag || !a.st[2].ufrag || !a.fin.ufrag) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chain_tail_wino_kernel, dim3(b_pad / 4), dim3(256), kTailWinoLds, s, a);
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(chain_tail_wino_kernel<AG>), 160 * 1024, &attr_done); e != hipSuccess) return e;
+    if (b_pad % AG) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chain_tail_wino_kernel<AG>, dim3(b_pad / AG), dim3(256), tail_wino_lds<AG>(), s, a);
     return hipGetLastError();
 }
-// three Winograd layers at L = 26 (8 xi x 4 chunks x 2 M-tiles x 4), the transposed conv (8 products x 16 k-steps x 4 M-tiles), final_conv.0 in
-// Winograd form, final_conv.1 (16 per M-tile of the image, shared between the four waves)
-double chain_tail_wino_exec_flop(int b_pad) { return (3 * 256.0 + 512.0 + 512.0 + 4.0 * Geo<52, 4>::NMT) * 4 * 2048.0 * (b_pad / 4); }
+hipError_t launch_chain_tail_wino(const ChainTailArgs& a, int b_pad, int agents_per_tile, hipStream_t s) {
+    if (!a.st[0].ufrag || !a.st[1].ufrag || !a.st[2].ufrag || !a.fin.ufrag) return hipErrorInvalidValue;
+    return agents_per_tile == 4 ? launch_chain_tail_wino_inst<4>(a, b_pad, s)
+         : agents_per_tile == 2 ? launch_chain_tail_wino_inst<2>(a, b_pad, s) : launch_chain_tail_wino_inst<1>(a, b_pad, s);
+}
+// three Winograd layers at L = 26, the transposed conv (8 products x 16 k-steps per M-tile of the L = 52 layout), final_conv.0 in Winograd form,
+// final_conv.1 (16 per M-tile of the image, shared between the four waves)
+template <int AG> static constexpr double tail_wino_mfma() {
+    return 3 * 128.0 * WGeo<26, AG>::NM + 128.0 * WGeo<52, AG>::NM + 128.0 * WGeo<52, AG>::NM + 4.0 * Geo<52, AG>::NMT;
+}
+double chain_tail_wino_exec_flop(int b_pad, int agents_per_tile) {
+    return (agents_per_tile == 4 ? tail_wino_mfma<4>() : agents_per_tile == 2 ? tail_wino_mfma<2>() : tail_wino_mfma<1>()) * 4 * 2048.0 * (b_pad / agents_per_tile);
+}
 
 }  // namespace cld

@@ -534,7 +534,7 @@ bool use_chains(cld_handle h, int b_pad) {
     if (h->precision != CLD_PRECISION_F32) return false;
     const int f = h->force_kernel[CLD_KERNEL_UNET];
     if (f == CLD_FORM_LAYERS) return false;
-    if (f == CLD_FORM_CHAIN || f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4 || f == CLD_FORM_CHAIN_WINO) return true;
+    if (f == CLD_FORM_CHAIN || f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4 || f == CLD_FORM_CHAIN_WINO || f == CLD_FORM_CHAIN_WINO2 || f == CLD_FORM_CHAIN_WINO1) return true;
     (void)b_pad;
     return true;              // measured faster than one launch per layer at every batch size (profiles/r03/chain_check.txt)
 }
@@ -546,13 +546,23 @@ int chain_tile(cld_handle h, int b_pad) {
     if (f == CLD_FORM_CHAIN_TILE4 || f == CLD_FORM_CHAIN_WINO) return 4;
     return b_pad <= kChainSmall ? 1 : 4;
 }
-// the four-agent chain tiles run their 64 -> 64 k5 layers in Winograd F(4, 5) form (chain_wino.hip) unless a test forces the direct
-// form of the k5 layers (CLD_KERNEL_CONV5) or of the chains (CLD_FORM_CHAIN_TILE4)
+// the chains run their 64 -> 64 k5 layers in Winograd F(4, 5) form (chain_wino.hip) unless a test forces the direct form of the k5 layers
+// (CLD_KERNEL_CONV5) or of the chains (CLD_FORM_CHAIN_TILE1 / CLD_FORM_CHAIN_TILE4)
+// agents per Winograd chain tile (chain_wino.hip): 4 (two workgroups per CU), 2 or 1 (three per CU)
+// (per U-Net evaluation, one / two / four agents: 240 / 262 / 310 us at 64 rows, 536 / 539 / 586 at 512, 700 / 709 / 729 at 768, 768 / 749 / 767 at 1,024,
+//  1,100 / 1,080 / 1,119 at 1,536, 1,344 / 1,314 / 1,314 at 2,048, 2,571 / 2,502 / 2,510 at 4,096; the direct one-agent tiles: 246 / 550 / 732 / 810)
+int chain_wino_tile(cld_handle h, int b_pad) {
+    const int f = h->force_kernel[CLD_KERNEL_UNET];
+    if (f == CLD_FORM_CHAIN_WINO) return 4;
+    if (f == CLD_FORM_CHAIN_WINO2) return 2;
+    if (f == CLD_FORM_CHAIN_WINO1) return 1;
+    return b_pad <= kChainSmall ? 1 : 2;
+}
 bool chain_wino(cld_handle h, int b_pad) {
     const int f = h->force_kernel[CLD_KERNEL_UNET];
-    if (f == CLD_FORM_CHAIN_WINO) return true;
+    if (f == CLD_FORM_CHAIN_WINO || f == CLD_FORM_CHAIN_WINO2 || f == CLD_FORM_CHAIN_WINO1) return true;
     if (f == CLD_FORM_CHAIN_TILE1 || f == CLD_FORM_CHAIN_TILE4) return false;
-    return chain_tile(h, b_pad) == 4 && h->force_kernel[CLD_KERNEL_CONV5] != CLD_FORM_DIRECT;
+    return h->force_kernel[CLD_KERNEL_CONV5] != CLD_FORM_DIRECT;
 }
 
 // One U-Net evaluation (temporal.py:122-180) on the padded latent `x` [b_pad,52,4]; leaves the
@@ -605,9 +615,9 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         h->launch_counter += 5;
         h->eval_alg_flop += 2.0 * b_pad * 52.0 * 64 * (20 + 3 * 320) + 2.0 * b_pad * 26.0 * 64 * 192 + 2.0 * b_pad * 52.0 * 64 * 4;
         const bool cw = chain_wino(h, b_pad);
-        h->eval_exec_flop += cw ? chain_head_wino_exec_flop(b_pad) : chain_head_exec_flop(b_pad, chain_tile(h, b_pad));
+        h->eval_exec_flop += cw ? chain_head_wino_exec_flop(b_pad, chain_wino_tile(h, b_pad)) : chain_head_exec_flop(b_pad, chain_tile(h, b_pad));
         h->eval_launches++;
-        e = cw ? launch_chain_head_wino(ca, b_pad, s) : launch_chain_head(ca, b_pad, chain_tile(h, b_pad), s);
+        e = cw ? launch_chain_head_wino(ca, b_pad, chain_wino_tile(h, b_pad), s) : launch_chain_head(ca, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
     } else {
     {   // block 0: conv(4 -> 64) | conv(64 -> 64) + residual_conv(x), the 1x1 projection of the latent evaluated in the epilogue
@@ -668,9 +678,9 @@ hipError_t run_unet(cld_handle h, const Ws& w, const float* x, int t_idx, int b_
         h->launch_counter += 6;
         h->eval_alg_flop += 2.0 * b_pad * 26.0 * 64 * (3 * 320) + 2.0 * b_pad * 52.0 * 64 * 128 + 2.0 * b_pad * 52.0 * 64 * 320 + 2.0 * b_pad * 52.0 * 4 * 64;
         const bool cw = chain_wino(h, b_pad);
-        h->eval_exec_flop += cw ? chain_tail_wino_exec_flop(b_pad) : chain_tail_exec_flop(b_pad, chain_tile(h, b_pad));
+        h->eval_exec_flop += cw ? chain_tail_wino_exec_flop(b_pad, chain_wino_tile(h, b_pad)) : chain_tail_exec_flop(b_pad, chain_tile(h, b_pad));
         h->eval_launches++;
-        e = cw ? launch_chain_tail_wino(ct, b_pad, s) : launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
+        e = cw ? launch_chain_tail_wino(ct, b_pad, chain_wino_tile(h, b_pad), s) : launch_chain_tail(ct, b_pad, chain_tile(h, b_pad), s);
         if (e != hipSuccess) return e;
         h->eps_in_buf7 = true;
     } else {
@@ -772,7 +782,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 5 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : (which == CLD_KERNEL_UNET ? 7 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }

@@ -147,10 +147,10 @@ struct ChainTailArgs {    // ups.1.0's second conv + ups.1.1 + ups.1.2 + final_c
 };
 hipError_t launch_chain_tail(const ChainTailArgs& a, int b_pad, int agents_per_tile /* 4 | 1 */, hipStream_t s);
 // the same two launches with their 64 -> 64 k5 layers in Winograd F(4, 5) form (chain_wino.hip; four-agent tiles; every k5 stage needs ufrag)
-hipError_t launch_chain_head_wino(const ChainHeadArgs& a, int b_pad, hipStream_t s);
-hipError_t launch_chain_tail_wino(const ChainTailArgs& a, int b_pad, hipStream_t s);
-double chain_head_wino_exec_flop(int b_pad);
-double chain_tail_wino_exec_flop(int b_pad);
+hipError_t launch_chain_head_wino(const ChainHeadArgs& a, int b_pad, int agents_per_tile /* 4 | 2 | 1 */, hipStream_t s);
+hipError_t launch_chain_tail_wino(const ChainTailArgs& a, int b_pad, int agents_per_tile /* 4 | 2 | 1 */, hipStream_t s);
+double chain_head_wino_exec_flop(int b_pad, int agents_per_tile);
+double chain_tail_wino_exec_flop(int b_pad, int agents_per_tile);
 // FLOP the MFMAs of a chain launch execute (2,048 per v_mfma_f32_16x16x4_f32, padded M-tiles and N columns included)
 double chain_head_exec_flop(int b_pad, int agents_per_tile);
 double chain_tail_exec_flop(int b_pad, int agents_per_tile);

@@ -468,11 +468,14 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 16x16x4 MFMA tiles */
 #define CLD_FORM_MFMA_QUAD 3  /* guide only: 8 agents per workgroup on the 16-block 4x4x1 fp32 MFMA (the form 2,048 agents run in) */
 #define CLD_FORM_LAYERS 1     /* CLD_KERNEL_UNET only */
-#define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only: chains, tile (4 agents | 1 agent per workgroup) by batch size */
+#define CLD_FORM_CHAIN 2      /* CLD_KERNEL_UNET only: chains, form and tile by batch size (= CLD_FORM_AUTO for exact-fp32 handles) */
 #define CLD_FORM_CHAIN_TILE1 3   /* CLD_KERNEL_UNET only: chains with one-agent tiles  */
 #define CLD_FORM_CHAIN_TILE4 4   /* CLD_KERNEL_UNET only: chains with four-agent tiles, every layer in the direct form (conv_chain.hip) */
 #define CLD_FORM_CHAIN_WINO 5    /* CLD_KERNEL_UNET only: chains with four-agent tiles, their 64 -> 64 k5 layers in Winograd F(4, 5) form
-                                  * (chain_wino.hip; what CLD_FORM_AUTO / CLD_FORM_CHAIN take above 944 rows per launch set) */
+                                  * (chain_wino.hip) */
+#define CLD_FORM_CHAIN_WINO2 6   /* CLD_KERNEL_UNET only: the Winograd chains with two-agent tiles (three workgroups per CU): what CLD_FORM_AUTO /
+                                  * CLD_FORM_CHAIN take above 944 rows per launch set */
+#define CLD_FORM_CHAIN_WINO1 7   /* CLD_KERNEL_UNET only: the Winograd chains with one-agent tiles: CLD_FORM_AUTO / CLD_FORM_CHAIN up to 944 rows */
 #define CLD_FORM_DIRECT 1     /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 #define CLD_FORM_WINOGRAD 2   /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);

@@ -14,7 +14,7 @@ for B in sizes:
     x = torch.randn(B, 52, 4, device="cuda", generator=g) * 2.0
     c = torch.randn(B, 256, device="cuda", generator=g)
     out, ms = {}, {}
-    for form in ("layers", "chain", "chain1", "chain4", "chainw"):
+    for form in ("layers", "chain", "chain1", "chain4", "chainw", "chainw2", "chainw1"):
         e.force_kernel("unet", form)
         out[form] = e.unet_forward(x, c, 37).clone()
         for _ in range(3):
@@ -38,5 +38,5 @@ for B in sizes:
     d = (out["chain"] - out["layers"]).abs().max().item()
     print(f"B={B}: max|chain - layers| = {d:.3e} (max|eps| = {out['layers'].abs().max().item():.3e}, finite={torch.isfinite(out['chain']).all().item()});"
           f" per evaluation incl. pack / cond-bias / head: layers {ms['layers']*1e3:.1f} us, chain {ms['chain']*1e3:.1f} us"
-          f" (one-agent tiles {ms['chain1']*1e3:.1f}, four-agent tiles {ms['chain4']*1e3:.1f}, four-agent Winograd tiles {ms['chainw']*1e3:.1f};"
+          f" (one-agent tiles {ms['chain1']*1e3:.1f}, four-agent tiles {ms['chain4']*1e3:.1f}, Winograd tiles of four / two / one agents {ms['chainw']*1e3:.1f} / {ms['chainw2']*1e3:.1f} / {ms['chainw1']*1e3:.1f};"
           f" max|chainw - chain4| = {(out['chainw'] - out['chain4']).abs().max().item():.3e})", flush=True)

@@ -1,7 +1,7 @@
 """GPU parity of the layer chains (csrc/conv_chain.hip, csrc/chain_wino.hip): the 64-channel levels of a U-Net evaluation as two launches
-whose tiles stay in LDS from layer to layer (exact-fp32 handles; the default at every batch size: one-agent tiles in the direct form up to
-944 rows per launch set, four-agent tiles with the 64 -> 64 k5 layers in Winograd F(4, 5) form above).  Every golden case runs in both:
-"chain" (at the fixtures' small batches: one-agent direct tiles) and "chainw" (the Winograd four-agent tiles forced).  Same bars as
+whose tiles stay in LDS from layer to layer (exact-fp32 handles; the default at every batch size, with the 64 -> 64 k5 layers in Winograd F(4, 5) form: one-agent tiles up to
+944 rows per launch set, two-agent tiles above).  Every golden case runs in the direct form ("chain1" / "chain4": one- / four-agent tiles) and with
+the Winograd tiles of four, two and one agents forced ("chainw", "chainw2", "chainw1").  Same bars as
 tests/test_gpu_parity.py: every case is run with the chains forced on at sizes the golden fixtures and the oracle cover, and the
 automatic choice is checked at a launch size that takes it.
 """
@@ -29,7 +29,7 @@ def _engine(n=100, jitter=True, form="chain"):
     return e
 
 
-FORMS = ["chain", "chainw"]
+FORMS = ["chain1", "chainw", "chainw2", "chainw1"]     # direct one-agent tiles; Winograd tiles of four / two / one agents
 
 
 @pytest.fixture(scope="module", params=FORMS)
@@ -151,15 +151,17 @@ def test_chains_are_the_default_and_agree_with_the_layer_launches(B):
     assert not torch.equal(auto, layers)             # two different kernels ran (their GroupNorm sums associate differently)
     assert float((auto - layers).abs().max()) <= 1e-5
     tiles = {}
-    for form in ("chain1", "chain4", "chainw"):      # one- and four-agent direct tiles, four-agent Winograd tiles (the batch size picks one)
+    for form in ("chain1", "chain4", "chainw", "chainw2", "chainw1"):      # one- and four-agent direct tiles; Winograd tiles of four / two / one agents
         e.force_kernel("unet", form)
         tiles[form] = e.unet_forward(x, cond, 41).clone()
-    assert torch.equal(auto, tiles["chain1" if B <= 944 else "chainw"])
+    assert torch.equal(auto, tiles["chainw1" if B <= 944 else "chainw2"])      # the library's own choice: Winograd tiles of one agent up to 944 rows, of two above
     assert float((tiles["chain1"] - tiles["chain4"]).abs().max()) <= 1e-5
     assert not torch.equal(tiles["chainw"], tiles["chain4"])
     dw = float((tiles["chainw"] - tiles["chain4"]).abs().max())
     print(f"Winograd chain vs direct chain at {B} rows: max|d eps| = {dw:.3e}")
     assert dw <= 1e-5
+    for form in ("chainw2", "chainw1"):              # the same Winograd layers on smaller tiles: every agent's sums are formed in the same order
+        assert torch.equal(tiles[form], tiles["chainw"]), form       # whatever the tile -- the result does not depend on the tile size, bit for bit
     rows = torch.tensor([0, 3, 4, B // 2 + 1, B - 2, B - 1])      # first / last tiles of the launch, both sides of a tile boundary
     ref = O.unet_forward(O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), x[rows], cond[rows],
                          torch.full((len(rows),), 41, dtype=torch.long))

@@ -136,7 +136,11 @@ def test_winograd_is_the_default_for_large_launch_sets_and_agrees_with_the_direc
     direct = e.unet_forward(x, cond, 41).clone()
     # (rows are padded to 16; launches of fewer than 512 whole items run as half items: up to 2,100 rows every instance does; at 3,200 rows
     # the 256-channel launches run 800 whole items -- a full generation of 512 and a partly filled one --, at 4,096 rows 1,024 = two full ones)
-    assert torch.equal(auto, wino if B >= 384 else direct)
+    if B >= 384:
+        assert torch.equal(auto, wino)
+    else:      # below 384 rows the L = 13 / 26 launches take the direct form, the layer chains the Winograd form (at every size, round 4): a mix of the two forced runs
+        assert not torch.equal(auto, wino) and not torch.equal(auto, direct)
+        assert float((auto - wino).abs().max()) <= 1e-5 and float((auto - direct).abs().max()) <= 1e-5
     assert not torch.equal(wino, direct)             # two different kernels ran
     assert float((wino - direct).abs().max()) <= 1e-5
     rows = torch.tensor([0, 3, 15, 16, B // 2 + 1, B - 2, B - 1])      # first / last workgroups, both sides of a 16-agent boundary
