@@ -9,7 +9,7 @@ from cld_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")
 e = Engine(100, dev); e.load_state_dict(synth.make_unet_weights(0)); e.finalize()
-e.force_kernel("unet", "chainw")
+e.force_kernel("unet", "chainw")      # the four-agent tile the phase table was first read on; the library itself takes two-agent tiles at this size
 x = torch.randn(B, 52, 4, device=dev); c = torch.randn(B, 256, device=dev)
 buf = torch.zeros(16 * 4096, dtype=torch.int64, device=dev)
 for rep in range(3):
