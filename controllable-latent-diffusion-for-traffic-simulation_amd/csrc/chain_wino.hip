@@ -18,6 +18,10 @@
 // (evaluated straight into the (agent, tile) layout), the stride-2 conv, the transposed conv (evaluated from the L = 26 image straight
 // into the L = 52 (agent, tile) layout: the four outputs of tile t are parities 0 | 1 of input rows 2 t and 2 t + 1) and final_conv.1.
 //
+// The kernels are templates over the agents per tile (WGeo<L, AG>): 4 (64 KB of V, two workgroups per CU), 2 (32 KB, three per CU: what the
+// library takes above 944 rows per launch set) and 1 (all of V resident in 32 KB: up to 944 rows).  Every agent's sums are formed in the same order
+// whatever the tile: the three sizes agree bit for bit.
+//
 // A row's result must not depend on its place in the workgroup (tests: shuffled batches reproduce their rows bit for bit): no implicit
 // contraction in this file -- every fused multiply-add below is written as one.
 #pragma clang fp contract(off)
