@@ -457,3 +457,26 @@ def test_collision_guided_step_at_the_batch_sizes_that_take_the_forward_sweep_pa
         err = float((auto.cpu() - ref).abs().max())
         print(f"   vs the oracle: {err:.3e}")
         assert err <= 2e-4 * sc_
+
+
+def test_map_collision_constructed_tie_is_shared_evenly(eng):
+    """ONE off-road sample of a 5-point line along the box with on-road neighbours at exactly equal distance on both sides (drivable
+    everywhere but the pixel column under the middle sample): upstream's torch.amin backward gives the whole pull to whichever
+    neighbour rounding made nearer -- parity unpinned by nature -- the kernel shares it evenly, so the pull along the
+    line cancels.  Value exact; gradient inside the interval the two candidates span (oracle.map_collision_grad_bounds), and zero along x."""
+    from oracle import cld_oracle as O
+    ext = torch.tensor([[4.0, 2.0, 1.5]])
+    rfa = torch.tensor([[[2.0, 0.0, 100.0], [0.0, 2.0, 100.0], [0.0, 0.0, 1.0]]])
+    dm = torch.ones(1, 200, 200, dtype=torch.bool)
+    dm[0, :, 100] = False
+    x = torch.zeros(1, 52, 6)
+    x[..., 0] = 0.25
+    spd = torch.tensor([5.0])
+    cfg = dict(extent=ext, raster_from_agent=rfa, drivable_map=dm, curr_speed=spd, weight=1.0, num_samp=1, num_points_lw=(5, 1))
+    loss, grad = eng.map_collision(x, cfg)
+    vref = O.map_collision_loss(x.reshape(1, 1, 52, 6), ext, rfa, dm, spd, num_points_lw=(5, 1))
+    assert float(vref) > 0.0 and abs(float(loss.cpu()) - float(vref)) <= 1e-6
+    lo, hi, tied = O.map_collision_grad_bounds(x.reshape(1, 1, 52, 6), ext, rfa, dm, spd, torch.ones(1, 1), num_points_lw=(5, 1))
+    got = grad.cpu().double().reshape(1, 1, 52, 6)[..., [0, 1, 3]]
+    assert bool(tied.all()) and float(torch.maximum(lo - got, got - hi).max()) <= 1e-9
+    assert float(got[..., 0].abs().max()) <= 1e-9 and float(lo[..., 0].max()) < 0.0 < float(hi[..., 0].min())

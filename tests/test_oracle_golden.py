@@ -496,6 +496,42 @@ def test_agent_collision_excluded_agents_vs_reference(golden, tag):
     assert abs(float(g[f"total_{tag}"][0]) - float(base["total_all" if si == 0 else "total_scene1"][0])) > 1e-4
 
 
+def test_map_collision_gradient_bounds_cover_autograd_and_a_constructed_tie(golden):
+    """`oracle.map_collision_grad_bounds` (the per-element bar of the GPU map-collision tests): (i) on the golden's scene the reference's own
+    gradient and the oracle's autograd gradient lie inside the intervals, which are degenerate (lo == hi) on all but a few steps; (ii) a
+    constructed tie -- ONE off-road sample of a 1 x 5 sample line with on-road neighbours at exactly equal distance on both sides (the case
+    ADVICE r3 names: parity unpinned by nature, torch.amin's backward follows rounding) -- is flagged, its interval spans both candidates'
+    gradients (opposite signs along the line), and autograd's answer is inside it."""
+    meta, g = golden("map_collision")
+    B, N = meta["B"], meta["N"]
+    db = map_inputs(B, meta["in_seed"])
+    traj = torch.from_numpy(synth.make_map_trajectories(B, N, db["curr_speed"].numpy(), meta["in_seed"]))
+    coef = torch.full((B, N), float(meta["weight"]) / (B * N))
+    lo, hi, tied = O.map_collision_grad_bounds(traj, db["extent"], db["raster_from_agent"], db["drivable_map"], db["curr_speed"], coef)
+    ref = torch.from_numpy(g["grad"]).double()[..., [0, 1, 3]]
+    gmax = float(ref.abs().max())
+    assert float(torch.maximum(lo - ref, ref - hi).max()) <= 1e-4 * gmax
+    assert 0 < int(tied.sum()) < 0.05 * tied.numel() and float((hi - lo)[~tied].abs().max()) == 0.0
+    # (ii) one agent, heading along +x, a 5-point line along its length (spacing 1 m); the map is drivable everywhere except the pixel
+    # column under the middle sample: samples 1 and 3 are on road at exactly 1 m on either side of the off-road sample 2
+    ext = torch.tensor([[4.0, 2.0, 1.5]])
+    rfa = torch.tensor([[[2.0, 0.0, 100.0], [0.0, 2.0, 100.0], [0.0, 0.0, 1.0]]])
+    dm = torch.ones(1, 200, 200, dtype=torch.bool)
+    x = torch.zeros(1, 1, 52, 6)
+    x[..., 0] = 0.25                       # sample 2 sits at x = 0.25 m -> pixel column int(100.5) = 100; its neighbours at -0.75 / 1.25 m -> 98 / 102
+    dm[0, :, 100] = False
+    spd = torch.tensor([5.0])
+    lo, hi, tied = O.map_collision_grad_bounds(x, ext, rfa, dm, spd, torch.ones(1, 1), num_points_lw=(5, 1))
+    assert bool(tied.all())
+    assert float(lo[..., 0].max()) < 0.0 < float(hi[..., 0].min())           # d / dx: pulled towards either neighbour
+    xg = x.reshape(1, 52, 6).clone().requires_grad_(True)
+    tot = O.scene_map_collision_total(xg, dict(extent=ext, raster_from_agent=rfa, drivable_map=dm, curr_speed=spd, scene_index=torch.zeros(1, dtype=torch.long),
+                                                 scene_weight=[1.0], num_points_lw=(5, 1)), 1)
+    (gr,) = torch.autograd.grad(tot, xg)
+    gr = gr.reshape(1, 1, 52, 6).double()[..., [0, 1, 3]]
+    assert float(torch.maximum(lo - gr, gr - hi).max()) <= 1e-9 and float(tot) > 0.0
+
+
 def guidance_multi_inputs(meta):
     B = meta["B"]
     inp = synth.make_inputs(B, meta["in_seed"])
