@@ -35,6 +35,7 @@ struct ConvLayer {
     ConvGeom g{};        // kc / nwn / ks are filled per launch by pick_tiling()
     bool has_a = false, has_b = false;   // which tilings have a kernel instance
     float *wfrag = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;
+    float* ufrag_edge = nullptr;   // the same with the raw taps 0..3 behind them, 12 planes per chunk (wino1d_edge.hip: whole-item launches)
     float* ufrag = nullptr;   // Winograd-domain filters G g of a k5 layer that has a Winograd form (exact-fp32 handles): as a launch of its own
                               // (wino1d_kernels.hip: wino_launch) or inside the layer chains (chain_wino.hip: the 64 -> 64 layers at L = 52 / 26)
     bool wino_launch = false;
@@ -443,7 +444,7 @@ bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
 void count_flop(cld_handle h, const ConvLayer& l, int b_pad, double* alg, double* exec) {
     const double cin = (double)(l.c1_real + l.c2);
     *alg = 2.0 * (double)b_pad * l.g.lm * (l.g.ntaps * cin) * l.c_out;
-    if (use_wino1d(h, l, b_pad)) *exec = 2.0 * (double)wino1d_gemm_rows(l.g.l_in, b_pad) * 8.0 * cin * l.c_out;
+    if (use_wino1d(h, l, b_pad)) *exec = 2.0 * (double)wino1d_row_planes(l.g.l_in, l.c_out, b_pad) * cin * l.c_out;
     else *exec = 2.0 * (double)b_pad * l.g.lm * (l.g.padc ? 20.0 : (double)(l.g.ntaps * (l.c1_pad + l.c2))) * l.c_out;
 }
 void count_launch(cld_handle h, const ConvLayer& l, int b_pad) {
@@ -458,6 +459,7 @@ hipError_t launch_one(cld_handle h, const ConvLayer& l, const ConvGeom& g, const
     if (use_wino1d(h, l, b_pad)) {
         ConvArgs w = a;
         w.wfrag = l.ufrag;
+        w.wfrag_edge = l.ufrag_edge;
         return launch_wino1d(w, l.g.l_in, b_pad, s);
     }
     return launch_conv(g, a, b_pad, s);
@@ -920,6 +922,11 @@ int cld_finalize(cld_handle h, void* stream) {
             };
             std::vector<float> upacked = pack_conv_weights(uget, c_out, cin_real, 8);
             UP(l.ufrag, upacked);
+            if (l.wino_launch) {      // wino1d_edge.hip: 12 planes per 16-channel chunk -- xi 0 .. 7, then the raw taps 0 .. 3 of the direct column
+                auto eget = [&](int co, int ci, int pl) -> float { return pl < 8 ? uget(co, ci, pl) : W[((size_t)co * cin_real + ci) * kw + (pl - 8)]; };
+                std::vector<float> epacked = pack_conv_weights(eget, c_out, cin_real, 12);
+                UP(l.ufrag_edge, epacked);
+            }
         }
         UP(l.bias, *getw(h, wname + ".bias"));
         if (epi == EPI_GN_MISH) {

@@ -43,6 +43,7 @@ struct ConvArgs {
     int c1_pad;      // c1_real rounded up to the K-chunk; chunks beyond c1_real read zeros
     int c2;          // channels of x2 (0 if none)
     const float* wfrag;   // MFMA-fragment-ordered weights (see pack_conv_weights)
+    const float* wfrag_edge;   // Winograd launches: the 12-plane fragments of wino1d_edge.hip (xi 0..7 | taps 0..3), or null
     const float* bias;    // [c_out] conv bias
     const float* gamma;   // [c_out] GroupNorm weight (EPI_GN_MISH)
     const float* beta;    // [c_out] GroupNorm bias
@@ -90,6 +91,9 @@ bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
 // L = 13 (256 -> 256, 128 -> 128, 128 -> 256, cat(256, 256) -> 128); a.wfrag = G g in pack_conv_weights layout with the 8 transform points as taps; exact-fp32 activations only
 bool wino1d_supported(int l_in, int c1, int c2, int c_out);      // c1 | c2: channels of the first | second (concatenated) source
 hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, hipStream_t s);
+long wino1d_row_planes(int l_in, int c_out, int b_pad);   // (GEMM rows x planes) a launch of that shape and size runs: x 2 C_in C_out = the FLOP its MFMAs execute
+hipError_t launch_wino1d_edge(const ConvArgs& a, int l_in, int b_pad, hipStream_t s);      // wino1d_edge.hip; a.wfrag = the 12-plane fragments
+long wino1d_edge_row_planes(int l_in, int b_pad);
 long wino1d_gemm_rows(int l_in, int b_pad);     // GEMM rows (64 per item, idle ones included) a launch runs its 8 transform-domain products over
 void set_lds_floor(size_t bytes);      // experiments only: minimum dynamic LDS per conv launch (0 = off)
 

@@ -30,7 +30,7 @@
 // ahead.  Epilogue in registers: A^T, conv bias, two-pass GroupNorm statistics (a group = 32 channels = two waves: DPP + permlane
 // sums inside the wave, 2 x 64 floats of LDS between the two), affine, Mish, vectors, residual, 16-byte stores.
 // Workgroup id -> (agent group, channel block) keeps the four channel blocks of an agent group on one XCD (they stage the same rows).
-#include "cld_kernels.h"
+#include "wino1d_common.h"
 
 #ifndef WINO1D_HALVES_BELOW
 #define WINO1D_HALVES_BELOW 512
@@ -46,68 +46,7 @@
 
 namespace cld {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-#ifdef CLD_STAMPS
-// diagnostic build: in-kernel cycle stamps (never compiled into the shipped library); scripts/wino1d_stamps.py reads them
-#define W1STAMP(k)                                                                                 \
-    do {                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (p.stamps && tid == 0) {                                                                \
-            unsigned long long t_;                                                                 \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-            p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                          \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    } while (0)
-#define W1STAMP_RT(k)                                                                              \
-    do {                                                                                           \
-        if (p.stamps && tid == 0) {                                                                \
-            unsigned long long t_;                                                                 \
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-            p.stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                          \
-        }                                                                                          \
-    } while (0)
-#else
-#define W1STAMP(k) do {} while (0)
-#define W1STAMP_RT(k) do {} while (0)
-#endif
-
 namespace {
-
-__device__ __forceinline__ v4f fma4(const v4f a, const float s, const v4f b) { return __builtin_elementwise_fma(a, v4f{s, s, s, s}, b); }      // a s + b
-
-__device__ __forceinline__ int hsw1(int k) { return ((k & 1) * 3) ^ (k >> 1); }      // wino_kernels.hip hsw
-
-#define W1_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
-// sum over the 4 lanes of a quad (the four tiles of an agent) and the 4 lane groups (channel quads), left in every lane involved
-__device__ __forceinline__ float agent_sum(float s) {
-    s += W1_DPP(s, 0xB1);       // quad_perm:[1,0,3,2]
-    s += W1_DPP(s, 0x4E);       // quad_perm:[2,3,0,1]
-    const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
-    const unsigned a16 = r16[0], b16 = r16[1];      // (scalars first: __builtin_bit_cast of a vector ELEMENT reads element 0)
-    s = __builtin_bit_cast(float, a16) + __builtin_bit_cast(float, b16);
-    const auto r32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, s), __builtin_bit_cast(unsigned, s), false, false);
-    const unsigned a32 = r32[0], b32 = r32[1];
-    return __builtin_bit_cast(float, a32) + __builtin_bit_cast(float, b32);
-}
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-// Mish = x n / (n + 2), n = e^x (e^x + 2) (conv_block.hip mish_f: one v_exp_f32 and one v_rcp_f32 per value), on register pairs so that
-// everything but the exponential, the reciprocal and the clamp is a packed fp32 instruction (two values per issue slot)
-__device__ __forceinline__ v2f mish2(const v2f x) {
-    const v2f c = v2f{fminf(x[0], 30.0f), fminf(x[1], 30.0f)} * v2f{1.4426950408889634f, 1.4426950408889634f};
-    const v2f e = {__builtin_amdgcn_exp2f(c[0]), __builtin_amdgcn_exp2f(c[1])};
-    const v2f two = {2.0f, 2.0f};
-    const v2f n = e * (e + two);
-    const v2f d = n + two;
-    const v2f r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    return (x * n) * r;
-}
-__device__ __forceinline__ v4f mish4(const v4f x) {
-    const v2f lo = mish2(v2f{x[0], x[1]}), hi = mish2(v2f{x[2], x[3]});
-    return v4f{lo[0], lo[1], hi[0], hi[1]};
-}
 
 // CIN input channels in one tensor (CS == CIN) or in two of CS = CIN / 2 channels each (torch.cat of the skip, temporal.py:167: a second
 // buffer descriptor); COUT output channels in blocks of 64 per workgroup
@@ -452,16 +391,6 @@ __global__ __launch_bounds__(256, HALVES ? WINO1D_HALF_WGS : 2) void wino1d_conv
     else wino1d_item<L, CIN, CS, COUT, 2>(p, b_pad, cb, grp * G::AG + half * (G::AG / 2), lds1);
 }
 
-// (L, C_in, channels per source, C_out): the k5 + GroupNorm + Mish layers of the L = 13 and L = 26 levels
-#define CLD_WINO1D_INSTANCES(X) \
-    X(13, 256, 256, 256)        \
-    X(13, 128, 128, 128)        \
-    X(13, 128, 128, 256)        \
-    X(13, 512, 256, 128)        \
-    X(26, 128, 128, 128)        \
-    X(26, 64, 64, 128)          \
-    X(26, 256, 128, 64)
-
 bool wino1d_supported(int l_in, int c1, int c2, int c_out) {
 #define X(L, CIN, CS, COUT) \
     if (l_in == L && c1 == CS && c1 + c2 == CIN && c_out == COUT) return true;
@@ -472,9 +401,33 @@ bool wino1d_supported(int l_in, int c1, int c2, int c_out) {
 
 long wino1d_gemm_rows(int l_in, int b_pad) { return l_in == 13 ? 4L * b_pad : 8L * b_pad; }      // 16 / 8 agents per 64-row item
 
+// Whole items (a 16-agent group at L = 13, 8 agents at L = 26) when they fill generations of 512 (two workgroups per CU); half items
+// below one generation and when the last generation would be at most half full (752 whole items are two rounds, 1,504 halves one and a
+// half).  Whole items run in wino1d_edge.hip's form (the ragged end of the sequence direct: 27 / 28 MFMAs per row where the items of
+// this file issue 32), half items here.
+#ifndef WINO1D_EDGE
+#define WINO1D_EDGE 1
+#endif
+static bool takes_halves(int l_in, int c_out, int b_pad) {
+    const int nfull = b_pad / (l_in == 13 ? 16 : 8) * (c_out / 64);
+    const int tail = nfull % WINO1D_HALVES_BELOW;
+    return nfull < WINO1D_HALVES_BELOW || (tail != 0 && tail <= WINO1D_HALVES_BELOW / 2);
+}
+long wino1d_row_planes(int l_in, int c_out, int b_pad) {
+    if (WINO1D_EDGE && !takes_halves(l_in, c_out, b_pad)) return wino1d_edge_row_planes(l_in, b_pad);
+    return 8L * wino1d_gemm_rows(l_in, b_pad);
+}
+
 template <int L, int CIN, int CS, int COUT>
 static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
     typedef W1Geo<L, CIN, CS, COUT> G;
+    const int groups = b_pad / G::AG, nfull = groups * G::NCB;
+    const bool halves = takes_halves(L, COUT, b_pad);
+    if (WINO1D_EDGE && !halves) {
+        ConvArgs e = a;
+        e.wfrag = a.wfrag_edge;
+        return e.wfrag ? launch_wino1d_edge(e, L, b_pad, s) : hipErrorInvalidValue;
+    }
     auto kern_whole = wino1d_conv_kernel<L, CIN, CS, COUT, 0>;
     auto kern_half = wino1d_conv_kernel<L, CIN, CS, COUT, 1>;
     constexpr size_t lds_half = (2 * (G::VBUF / 2) + G::XCH) * sizeof(float);
@@ -482,11 +435,6 @@ static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s
     if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern_whole), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
     if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern_half), (int)lds_half, &attr_done_h); e != hipSuccess) return e;
     if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
-    const int groups = b_pad / G::AG, nfull = groups * G::NCB;
-    // whole items when they fill generations of 512 (two workgroups per CU); halves below one generation and when the last generation
-    // would be at most half full (752 whole items are two rounds, 1,504 halves one and a half)
-    const int tail = nfull % WINO1D_HALVES_BELOW;
-    const int halves = (nfull < WINO1D_HALVES_BELOW || (tail != 0 && tail <= WINO1D_HALVES_BELOW / 2)) ? 1 : 0;
     if (halves) hipLaunchKernelGGL(kern_half, dim3(nfull << 1), dim3(256), lds_half, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
     else hipLaunchKernelGGL(kern_whole, dim3(nfull), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
     return hipGetLastError();
