@@ -413,16 +413,16 @@ static bool takes_halves(int l_in, int c_out, int b_pad) {
     const int tail = nfull % WINO1D_HALVES_BELOW;
     return nfull < WINO1D_HALVES_BELOW || (tail != 0 && tail <= WINO1D_HALVES_BELOW / 2);
 }
-long wino1d_row_planes(int l_in, int c_out, int b_pad) {
-    if (WINO1D_EDGE && !takes_halves(l_in, c_out, b_pad)) return wino1d_edge_row_planes(l_in, b_pad);
+long wino1d_row_planes(int l_in, int c_out, int b_pad, bool whole_items) {
+    if (WINO1D_EDGE && (whole_items || !takes_halves(l_in, c_out, b_pad))) return wino1d_edge_row_planes(l_in, b_pad);
     return 8L * wino1d_gemm_rows(l_in, b_pad);
 }
 
 template <int L, int CIN, int CS, int COUT>
-static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
+static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, bool whole_items, hipStream_t s) {
     typedef W1Geo<L, CIN, CS, COUT> G;
     const int groups = b_pad / G::AG, nfull = groups * G::NCB;
-    const bool halves = takes_halves(L, COUT, b_pad);
+    const bool halves = !(WINO1D_EDGE && whole_items) && takes_halves(L, COUT, b_pad);
     if (WINO1D_EDGE && !halves) {
         ConvArgs e = a;
         e.wfrag = a.wfrag_edge;
@@ -440,10 +440,10 @@ static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, hipStream_t s) {
+hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, bool whole_items, hipStream_t s) {
     if (b_pad < 16 || b_pad % 16 || a.res4_x || a.c1_real != a.c1_pad || (a.c2 != 0) != (a.x2 != nullptr)) return hipErrorInvalidValue;
 #define X(L, CIN, CS, COUT) \
-    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_inst<L, CIN, CS, COUT>(a, b_pad, s);
+    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_inst<L, CIN, CS, COUT>(a, b_pad, whole_items, s);
     CLD_WINO1D_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -462,7 +462,8 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_KERNEL_CONTEXT 4  /* the 3x3 / stride-1 convolutions of the ContextEncoder: CLD_FORM_AUTO / CLD_FORM_WINOGRAD Winograd F(2x2, 3x3)
                                * (wino_kernels.hip), CLD_FORM_DIRECT the implicit-GEMM kernel the other convolutions use */
 #define CLD_KERNEL_CONV5 5    /* the Conv1d(k5) + GroupNorm + Mish launches of the L = 13 / 26 levels of a U-Net evaluation (exact-fp32 handles): CLD_FORM_AUTO
-                               * by batch size, CLD_FORM_DIRECT conv_block.hip, CLD_FORM_WINOGRAD Winograd F(4, 5) (wino1d_kernels.hip) */
+                               * by batch size, CLD_FORM_DIRECT conv_block.hip, CLD_FORM_WINOGRAD Winograd F(4, 5) (wino1d_edge.hip / wino1d_kernels.hip by launch size),
+                               * CLD_FORM_WINOGRAD_WHOLE wino1d_edge.hip at every size */
 #define CLD_FORM_AUTO 0       /* by batch size (default) */
 #define CLD_FORM_VALU 1       /* one or two agents per workgroup, gate rows in registers */
 #define CLD_FORM_MFMA 2       /* 16 agents per workgroup, gate products as fp32 16x16x4 MFMA tiles */
@@ -478,6 +479,8 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_FORM_CHAIN_WINO1 7   /* CLD_KERNEL_UNET only: the Winograd chains with one-agent tiles: CLD_FORM_AUTO / CLD_FORM_CHAIN up to 944 rows */
 #define CLD_FORM_DIRECT 1     /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 #define CLD_FORM_WINOGRAD 2   /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
+#define CLD_FORM_WINOGRAD_WHOLE 3   /* CLD_KERNEL_CONV5 only: Winograd with whole items at every launch size (wino1d_edge.hip: what CLD_FORM_WINOGRAD takes
+                                     * by itself once a launch fills two workgroups per CU; below that it runs half items, wino1d_kernels.hip) */
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form);
 
 /* CLD_PRECISION_* the handle runs with. */

@@ -27,15 +27,21 @@ def _engine(n=100, jitter=True, form="winograd"):
     return e
 
 
-@pytest.fixture(scope="module")
-def eng():
-    return _engine()
+# "winograd": half items (wino1d_kernels.hip) at these sizes; "winograd_whole": wino1d_edge.hip's whole items, which a launch takes by itself
+# only from two workgroups per CU (the large-batch cases below) -- forced here so that the golden fixtures and the oracle cover that kernel too
+ITEM_FORMS = ["winograd", "winograd_whole"]
 
 
+@pytest.fixture(scope="module", params=ITEM_FORMS)
+def eng(request):
+    return _engine(form=request.param)
+
+
+@pytest.mark.parametrize("form", ITEM_FORMS)
 @pytest.mark.parametrize("tag", ["default", "jitter"])
-def test_winograd_unet_forward_golden(golden, tag):
+def test_winograd_unet_forward_golden(golden, tag, form):
     meta, g = golden(f"unet_forward_{tag}")
-    e = _engine(100, meta["affine_jitter"])
+    e = _engine(100, meta["affine_jitter"], form)
     B = meta["B"]
     x = torch.from_numpy(synth.normal(meta["in_seed"], "unet_x", (B, 52, 4))) * 3.0
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
@@ -73,10 +79,11 @@ def test_winograd_ddpm_step_golden(golden, eng):
         assert np.abs(xn.cpu().numpy() - g[f"x_next_t{i}"]).max() <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("form", ITEM_FORMS)
 @pytest.mark.parametrize("n,jitter", [(10, True), (50, True), (100, True)])
-def test_winograd_full_chain_golden(golden, n, jitter):
+def test_winograd_full_chain_golden(golden, n, jitter, form):
     meta, g = golden(f"sample_n{n}_{'jitter' if jitter else 'default'}")
-    e = _engine(n, jitter)
+    e = _engine(n, jitter, form)
     B = meta["B"]
     cond = torch.from_numpy(synth.make_inputs(B, meta["in_seed"])["cond_feat"])
     nz = synth.make_noise(B, n, meta["noise_seed"])
@@ -89,7 +96,8 @@ def test_winograd_full_chain_golden(golden, n, jitter):
     assert np.allclose(logp.cpu().numpy(), g["log_prob_final"], atol=1e-4)
 
 
-def test_winograd_small_chain_absolute_bar(golden):
+@pytest.mark.parametrize("form", ITEM_FORMS)
+def test_winograd_small_chain_absolute_bar(golden, form):
     """north_star's literal bar (<= 1e-3 ABSOLUTE per latent element over 100 steps) with the Winograd form on."""
     from cld_amd.engine import Engine
     from tests.test_oracle_golden import small_chain_inputs
@@ -98,7 +106,7 @@ def test_winograd_small_chain_absolute_bar(golden):
     e = Engine(n_timesteps=meta["n_timesteps"], device="cuda:0")
     e.load_state_dict(w)
     e.finalize()
-    e.force_kernel("conv5", "winograd")
+    e.force_kernel("conv5", form)
     cond = torch.from_numpy(synth.make_inputs(meta["B"], meta["in_seed"])["cond_feat"])
     x0, x1, logp = e.sample(x_T, cond, noise=noise)
     for got, k in ((x0, "pred_traj"), (x1, "x1")):
@@ -122,7 +130,7 @@ def test_winograd_cfg_golden(golden):
         assert float(np.abs(got.cpu().numpy() - g[k]).max()) <= 1e-3 * scale
 
 
-@pytest.mark.parametrize("B", [300, 600, 1024, 2100, 3200, 4096])
+@pytest.mark.parametrize("B", [300, 600, 1024, 2100, 3200, 3205, 4096])
 def test_winograd_is_the_default_for_large_launch_sets_and_agrees_with_the_direct_form(B):
     from oracle import cld_oracle as O
     e = _engine(100, True, "auto")
@@ -142,6 +150,13 @@ def test_winograd_is_the_default_for_large_launch_sets_and_agrees_with_the_direc
         assert not torch.equal(auto, wino) and not torch.equal(auto, direct)
         assert float((auto - wino).abs().max()) <= 1e-5 and float((auto - direct).abs().max()) <= 1e-5
     assert not torch.equal(wino, direct)             # two different kernels ran
+    e.force_kernel("conv5", "winograd_whole")
+    whole = e.unet_forward(x, cond, 41).clone()
+    if B == 4096:                                    # 512 whole items or more in every k5 launch of the two levels: what the size rule takes is the whole-item kernel
+        assert torch.equal(whole, wino)
+    elif B <= 2100:                                  # every launch in half items (the other Winograd kernel: its fourth tile where this one has a direct column)
+        assert not torch.equal(whole, wino)
+    assert float((whole - wino).abs().max()) <= 1e-5
     assert float((wino - direct).abs().max()) <= 1e-5
     rows = torch.tensor([0, 3, 15, 16, B // 2 + 1, B - 2, B - 1])      # first / last workgroups, both sides of a 16-agent boundary
     ref = O.unet_forward(O.to_torch(synth.make_unet_weights(0, affine_jitter=True)), x[rows], cond[rows],
