@@ -271,6 +271,10 @@ def main():
                 peak = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
                 traffic = pmc_traffic(rows) if not split else (None, None)
                 wino = not split and rows >= 384          # csrc/cld_api.hip kWino1dMinRows: the Winograd F(4, 5) form of these launches
+
+                def wino_whole(r):                        # csrc/wino1d_kernels.hip takes_halves: whole items from two workgroups per CU
+                    nfull = (r + 15) // 16 * 4
+                    return not (nfull < 512 or 0 < nfull % 512 <= 256)
                 what = ("Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; 7 launches per U-Net evaluation, all with 256 input channels "
                         "-- every 10th evaluation timed")
                 # `achieved` / `frac`: FLOP the MFMA pipe EXECUTED (counted by the library for the form each timed launch took:
@@ -282,7 +286,8 @@ def main():
                         "frac": round(ex_ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],
                         "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                        else "v_mfma_f32_16x16x4_f32 dense peak"),
-                        "kernel": ("wino1d_conv_kernel<13,256,256,256,0> (%s)" % what if wino else
+                        "kernel": (("wino1d_edge_kernel<13,256,256,256> (%s; rows of agents, output 12 of every row in the direct form)" if wino_whole(rows)
+                                    else "wino1d_conv_kernel<13,256,256,256,1> (%s; half items)") % what if wino else
                                    "conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0,0> (%s; tiling picked by the rows per launch)"
                                    % ("4,1" if rows >= 2048 else ("4,2" if rows >= 1024 else "2,2"), what)),
                         "agents_per_launch": rows, "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),

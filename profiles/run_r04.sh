@@ -31,7 +31,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 fi
 [ "$PART" = 1 ] && { ls $OUT | head -80; exit 0; }
 ARGS="$R/bench.py --steps 1 --warmup 0 --denoise-steps 10 --no-cpu-baseline --no-profile --no-extras"
-CLD_LIB_PATH=$R/controllable-latent-diffusion-for-traffic-simulation_amd/libcld_stamps.so python3 $R/scripts/wino1d_stamps.py 4096 3 10 13 14 > $OUT/wino1d_stamps_4096.txt 2>&1
+CLD_LIB_PATH=$R/controllable-latent-diffusion-for-traffic-simulation_amd/libcld_stamps.so python3 $R/scripts/wino1d_stamps.py 4096 3 8 13 18 > $OUT/wino1d_stamps_4096.txt 2>&1
 CLD_LIB_PATH=$R/controllable-latent-diffusion-for-traffic-simulation_amd/libcld_stamps.so python3 $R/scripts/chainw_stamps.py 4096 > $OUT/chainw_stamps_4096.txt 2>&1
 $R/scripts/ubench/mfma_covalu > $OUT/mfma_covalu.txt 2>&1
 bash $R/scripts/wino_pmc.sh winograd > $OUT/ctx_clock_mfma_busy.txt 2>&1; bash $R/scripts/wino_pmc.sh direct >> $OUT/ctx_clock_mfma_busy.txt 2>&1

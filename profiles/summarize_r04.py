@@ -46,14 +46,14 @@ def avg(kernel_sub, counter):
 
 
 out = {}
-dom = "wino1d_conv_kernel<13, 256, 256, 256, 0>"     # the 256 -> 256 k5 launches in their Winograd form: the headline launches 4,096 rows (2 x 2,048 agents, CFG)
+dom = "wino1d_edge_kernel<13, 256, 256, 256>"     # the 256 -> 256 k5 launches in their Winograd form: the headline launches 4,096 rows (2 x 2,048 agents, CFG)
 fe, wr = avg(dom, "FETCH_SIZE"), avg(dom, "WRITE_SIZE")
 if fe is not None and wr is not None:
     out = {"kernel": "void cld::" + dom + "(cld::ConvArgs, int, int)", "batch_agents": 4096,
            "hbm_bytes_per_launch": int(2 * fe * 1024 + wr * 1024), "fetch_bytes_x2_corrected": int(2 * fe * 1024), "write_bytes": int(wr * 1024),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (profiles/run_r04.sh), KiB -> bytes, FETCH_SIZE doubled per "
                    "MI355X_MICROARCH.md; average over the launches of this instance (256 -> 256 channels, k5, L = 13)",
-           "algorithmic_bytes_per_launch": {"activations_in": 54525952, "weights_winograd_domain_8_of_5_taps": 2097152, "output": 54525952, "residual_in_4_of_7_launches": 31157687}}
+           "algorithmic_bytes_per_launch": {"activations_in": 54525952, "weights_8_transform_planes_plus_3_taps": 2883584, "output": 54525952, "residual_in_4_of_7_launches": 31157687}}
     lc, la = avg(dom, "SQ_LDS_BANK_CONFLICT"), avg(dom, "SQ_LDS_IDX_ACTIVE")
     if lc is not None and la:
         out["lds_bank_conflict_cycles"], out["lds_idx_active_cycles"], out["lds_conflict_share"] = lc, la, round(lc / la, 4)
