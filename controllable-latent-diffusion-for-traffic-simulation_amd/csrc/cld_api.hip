@@ -432,7 +432,12 @@ bool conv5_takes_winograd(int l_in, int c1, int c2, int c_out, long b_pad, int f
     if (!wino1d_supported(l_in, c1, c2, c_out) || forced == CLD_FORM_DIRECT) return false;
     const long widest = c1 > c_out ? c1 : c_out;      // the Winograd kernel addresses its tensors with 32-bit byte offsets (per source tensor)
     if (b_pad * l_in * widest * 4 >= (1L << 31)) return false;
-    return forced == CLD_FORM_WINOGRAD || forced == CLD_FORM_WINOGRAD_WHOLE || b_pad >= kWino1dMinRows;
+    return forced == CLD_FORM_WINOGRAD || forced == CLD_FORM_WINOGRAD_WHOLE || forced == CLD_FORM_WINOGRAD_KSPLIT || b_pad >= kWino1dMinRows;
+}
+// what a test forced about the items of the Winograd launches: 0 = by size, 1 = whole items, 2 = whole items of eight waves
+int wino_item_form(cld_handle h) {
+    const int f = h->force_kernel[CLD_KERNEL_CONV5];
+    return f == CLD_FORM_WINOGRAD_WHOLE ? 1 : f == CLD_FORM_WINOGRAD_KSPLIT ? 2 : 0;
 }
 bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
     if (!l.ufrag || !l.wino_launch) return false;
@@ -444,7 +449,7 @@ bool use_wino1d(cld_handle h, const ConvLayer& l, int b_pad) {
 void count_flop(cld_handle h, const ConvLayer& l, int b_pad, double* alg, double* exec) {
     const double cin = (double)(l.c1_real + l.c2);
     *alg = 2.0 * (double)b_pad * l.g.lm * (l.g.ntaps * cin) * l.c_out;
-    if (use_wino1d(h, l, b_pad)) *exec = 2.0 * (double)wino1d_row_planes(l.g.l_in, l.c_out, b_pad, h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_WINOGRAD_WHOLE) * cin * l.c_out;
+    if (use_wino1d(h, l, b_pad)) *exec = 2.0 * (double)wino1d_row_planes(l.g.l_in, l.c_out, b_pad, wino_item_form(h)) * cin * l.c_out;
     else *exec = 2.0 * (double)b_pad * l.g.lm * (l.g.padc ? 20.0 : (double)(l.g.ntaps * (l.c1_pad + l.c2))) * l.c_out;
 }
 void count_launch(cld_handle h, const ConvLayer& l, int b_pad) {
@@ -460,7 +465,7 @@ hipError_t launch_one(cld_handle h, const ConvLayer& l, const ConvGeom& g, const
         ConvArgs w = a;
         w.wfrag = l.ufrag;
         w.wfrag_edge = l.ufrag_edge;
-        return launch_wino1d(w, l.g.l_in, b_pad, h->force_kernel[CLD_KERNEL_CONV5] == CLD_FORM_WINOGRAD_WHOLE, s);
+        return launch_wino1d(w, l.g.l_in, b_pad, wino_item_form(h), s);
     }
     return launch_conv(g, a, b_pad, s);
 }
@@ -784,13 +789,13 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE || which == CLD_KERNEL_CONV5 ? 3 : (which == CLD_KERNEL_UNET ? 7 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : which == CLD_KERNEL_CONV5 ? 4 : (which == CLD_KERNEL_UNET ? 7 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }
 
 int cld_debug_conv5_form(int32_t l_in, int32_t c1, int32_t c2, int32_t c_out, int64_t rows, int32_t forced_form) {
-    if (l_in < 1 || c1 < 1 || c2 < 0 || c_out < 1 || rows < 0 || forced_form < 0 || forced_form > 3) return CLD_ERR_ARG;
+    if (l_in < 1 || c1 < 1 || c2 < 0 || c_out < 1 || rows < 0 || forced_form < 0 || forced_form > 4) return CLD_ERR_ARG;
     return conv5_takes_winograd(l_in, c1, c2, c_out, (long)((rows + 15) / 16 * 16), forced_form) ? CLD_FORM_WINOGRAD : CLD_FORM_DIRECT;
 }
 

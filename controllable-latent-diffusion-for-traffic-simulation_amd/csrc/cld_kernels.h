@@ -90,9 +90,9 @@ bool conv_pair_supported(const ConvGeom& a, const ConvGeom& b);
 // Conv1d(k5, pad 2) + GroupNorm + Mish [+ vectors] [+ residual] by Winograd F(4, 5) (wino1d_kernels.hip): the 256 -> 256 launches at
 // L = 13 (256 -> 256, 128 -> 128, 128 -> 256, cat(256, 256) -> 128); a.wfrag = G g in pack_conv_weights layout with the 8 transform points as taps; exact-fp32 activations only
 bool wino1d_supported(int l_in, int c1, int c2, int c_out);      // c1 | c2: channels of the first | second (concatenated) source
-hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, bool whole_items, hipStream_t s);      // whole_items: at every size (tests); otherwise by size
-long wino1d_row_planes(int l_in, int c_out, int b_pad, bool whole_items);   // (GEMM rows x planes) a launch of that shape and size runs: x 2 C_in C_out = the FLOP its MFMAs execute
-hipError_t launch_wino1d_edge(const ConvArgs& a, int l_in, int b_pad, hipStream_t s);      // wino1d_edge.hip; a.wfrag = the 12-plane fragments
+hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, int item_form, hipStream_t s);      // item_form: 0 by size; 1 whole items, 2 whole items of eight waves, at every size (tests)
+long wino1d_row_planes(int l_in, int c_out, int b_pad, int item_form);   // (GEMM rows x planes) a launch of that shape and size runs: x 2 C_in C_out = the FLOP its MFMAs execute
+hipError_t launch_wino1d_edge(const ConvArgs& a, int l_in, int b_pad, bool k_split, hipStream_t s);      // wino1d_edge.hip; a.wfrag = the 12-plane fragments; k_split: eight waves per item
 long wino1d_edge_row_planes(int l_in, int b_pad);
 long wino1d_gemm_rows(int l_in, int b_pad);     // GEMM rows (64 per item, idle ones included) a launch runs its 8 transform-domain products over
 void set_lds_floor(size_t bytes);      // experiments only: minimum dynamic LDS per conv launch (0 = off)

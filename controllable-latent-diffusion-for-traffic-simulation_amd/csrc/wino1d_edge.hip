@@ -51,14 +51,23 @@ struct E1Geo {
 
 }  // namespace
 
-template <int L, int CIN, int CS, int COUT>
-__global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, const int b_pad, const int xcd_map) {
+// KS = 1: four waves, two workgroups per CU.  KS = 2 (launches of about one item per CU, where a second workgroup per CU does not exist): eight
+// waves -- waves 4 .. 7 run the second half of the input channels of the same item on V images of their own, so that every SIMD has two
+// waves and neither the staging nor the weight traffic is duplicated (the half items of wino1d_kernels.hip fetch every plane twice); their
+// accumulators meet those of waves 0 .. 3 through the LDS the images leave free after the last chunk, and waves 0 .. 3 run the epilogue alone.
+template <int L, int CIN, int CS, int COUT, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void wino1d_edge_kernel(const ConvArgs p, const int b_pad, const int xcd_map) {
     typedef E1Geo<L, CIN, CS, COUT> G;
     extern __shared__ __attribute__((aligned(16))) float lds1[];
     constexpr int VB = G::VB;
-    float* xch = lds1 + 2 * VB;
+    float* xch = lds1 + 2 * KS * VB;
     const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, kk = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave8 & 3, kh = KS == 1 ? 0 : wave8 >> 2;          // role within the item (staging tile / output-channel tile), half of the input channels
+    static_assert(KS == 1 || KS == 2, "one or two halves of the input channels");
+    static_assert((G::NCH / KS) % 2 == 0, "chunk pairs are unrolled within a half");
+    constexpr int NCK = G::NCH / KS;                      // chunks per half
+    const int c_first = kh * NCK;
     int cb, grp;
     {
         const int e = blockIdx.x;
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
     const int wofs = rr * 16 + ((((rr >> 2) & 3) ^ hsw1(cq)) << 2);
     // B^T d in four pieces (xi pairs share their even / odd halves), each stored as it is formed; wave 3 stores its rows as they are
     auto transform_piece = [&](const int k, const int buf) {
-        float* vb = lds1 + buf * VB + wofs;
+        float* vb = lds1 + (2 * kh + buf) * VB + wofs;
         if (wave == 3) {
             if (k < G::NT) *reinterpret_cast<v4f*>(vb + (24 + k) * 256) = d[k];
             return;
@@ -140,10 +149,10 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
         for (int m = 0; m < 3; ++m) acc[xi][m] = v4f{0.f, 0.f, 0.f, 0.f};
     v4f bq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bq[i] = wload(i);
+    for (int i = 0; i < 4; ++i) bq[i] = wload(c_first * 12 + i);
 
 #pragma unroll
-    for (int i = 0; i < 8; ++i) patch_load(i, 0);
+    for (int i = 0; i < 8; ++i) patch_load(i, c_first);
 #pragma unroll
     for (int k = 0; k < 4; ++k) transform_piece(k, 0);
     __syncthreads();
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
     // three), weight planes four ahead (ring slot = plane & 3; plane 11 of the L = 13 shapes is a slot that is skipped); the next chunk's
     // rows are requested during the first eight items and transformed during xi = 4 .. 7
     auto mfma_block = [&](const int buf, const int c, const bool stage) {
-        const int bo = buf * (VB * 4);
+        const int bo = (2 * kh + buf) * (VB * 4);
         auto frag = [&](const int it) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + it * 1024); };
         v4f ar[3];
         ar[0] = frag(0);
@@ -186,15 +195,38 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
     };
 
 #pragma clang loop unroll(disable)
-    for (int c = 0; c < G::NCH; c += 2) {
+    for (int c = c_first; c < c_first + NCK; c += 2) {
         mfma_block(0, c, true);
         __syncthreads();
-        const bool more = c + 2 < G::NCH;
+        const bool more = c + 2 < c_first + NCK;
         mfma_block(1, c + 1, more);
         __syncthreads();
         if (c == 0) W1STAMP(5);
     }
     W1STAMP(2);
+    if constexpr (KS == 2) {
+        // the two halves' accumulators: waves 4 .. 7 leave theirs in LDS (the images are dead: the loop ended on a barrier), [wave][tile][lane] x 16 bytes
+        float* red = lds1 + (wave * 25 * 64 + lane) * 4;
+        if (kh == 1) {
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) *reinterpret_cast<v4f*>(red + (3 * xi + m) * 256) = acc[xi][m];
+            *reinterpret_cast<v4f*>(red + 24 * 256) = accd;
+        }
+        __syncthreads();
+        if (kh == 0) {      // (three tiles at a time: read all at once, the 25 partners would need 100 registers next to the accumulators)
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc[xi][m] += *reinterpret_cast<const v4f*>(red + (3 * xi + m) * 256);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            accd += *reinterpret_cast<const v4f*>(red + 24 * 256);
+        }
+    }
+  constexpr bool PAIR = G::GS == 32;
+  if (kh == 0) {
 
     // ---- epilogue.  Lane: channels n4 .. n4 + 3 of row i16: outputs p0 + 4 m + o (m < 3, o < 4) and pd ----
     v4f Y[13];
@@ -209,8 +241,12 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
         Y[4 * m + 3] = (fma4(m56, 0.125f, fma4(m34, 8.0f, m12)) + acc[7][m]) + bias;
     }
     Y[12] = accd + bias;
-    // every operand of the second half of the epilogue is requested now, behind the output transform (wino1d_kernels.hip)
+    // every operand of the second half of the epilogue is requested now, behind the output transform (wino1d_kernels.hip) -- and not before it:
+    // the residual loads sit in a conditional block of their own, which the compiler otherwise places in front of the transform (the eight-wave
+    // instances spilled 40 .. 56 registers that way); a compiler-level memory fence that consumes Y pins the order
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int o = 0; o < 13; ++o) asm volatile("" : "+v"(Y[o]) : : "memory");
     const int ybytes = b_pad * L * COUT * 4;
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.y), 0, ybytes, 0x00020000);
@@ -235,7 +271,6 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
     // (4 channels x 13 outputs) -> the group's total: channel lanes by permlane swaps (16 lanes apart: the other channel quad of an
     // 8-channel group; 32 apart: the rest of the wave's 16 channels), the other half of the agent at L = 26 by a DPP swap of neighbouring
     // lanes, the other wave of a 32-channel group through LDS
-    constexpr bool PAIR = G::GS == 32;
     const float inv = 1.0f / (float)(G::GS * L);
     auto group_total = [&](float sv, float* scratch) {
         const auto r16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, sv), __builtin_bit_cast(unsigned, sv), false, false);
@@ -291,27 +326,35 @@ __global__ __launch_bounds__(256, 2) void wino1d_edge_kernel(const ConvArgs p, c
     }
     W1STAMP(4);
     W1STAMP_RT(9);
+  } else if (PAIR) {      // waves 4 .. 7: the two barriers of the epilogue's statistics passes
+    __syncthreads();
+    __syncthreads();
+  }
 }
 
 long wino1d_edge_row_planes(int l_in, int b_pad) { return l_in == 13 ? 27L * b_pad : 56L * b_pad; }      // (GEMM rows x planes) of a launch: 27 per agent, 2 x 28 per agent
 
 template <int L, int CIN, int CS, int COUT>
-static hipError_t launch_wino1d_edge_inst(const ConvArgs& a, int b_pad, hipStream_t s) {
+static hipError_t launch_wino1d_edge_inst(const ConvArgs& a, int b_pad, bool k_split, hipStream_t s) {
     typedef E1Geo<L, CIN, CS, COUT> G;
-    auto kern = wino1d_edge_kernel<L, CIN, CS, COUT>;
-    static unsigned long long attr_done = 0;      // one bit per device
+    auto kern = wino1d_edge_kernel<L, CIN, CS, COUT, 1>;
+    auto kern2 = wino1d_edge_kernel<L, CIN, CS, COUT, 2>;
+    constexpr size_t lds2 = (4 * G::VB + G::XCH) * sizeof(float);
+    static unsigned long long attr_done = 0, attr_done2 = 0;      // one bit per device
     if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, &attr_done); e != hipSuccess) return e;
+    if (hipError_t e = set_max_lds_once(reinterpret_cast<const void*>(kern2), (int)lds2, &attr_done2); e != hipSuccess) return e;
     if ((long)b_pad * L * CS * 4 >= (1L << 31) || (long)b_pad * L * COUT * 4 >= (1L << 31)) return hipErrorInvalidValue;      // byte offsets are 32-bit
     const int groups = b_pad / G::AG;
-    hipLaunchKernelGGL(kern, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
+    if (k_split) hipLaunchKernelGGL(kern2, dim3(groups * G::NCB), dim3(512), lds2, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
+    else hipLaunchKernelGGL(kern, dim3(groups * G::NCB), dim3(256), G::LDS_BYTES, s, a, b_pad, groups % 8 == 0 ? 1 : 0);
     return hipGetLastError();
 }
 
 // a.wfrag: the 12-plane fragments (ConvLayer::ufrag_edge)
-hipError_t launch_wino1d_edge(const ConvArgs& a, int l_in, int b_pad, hipStream_t s) {
+hipError_t launch_wino1d_edge(const ConvArgs& a, int l_in, int b_pad, bool k_split, hipStream_t s) {
     if (b_pad < 16 || b_pad % 16 || a.res4_x || a.c1_real != a.c1_pad || (a.c2 != 0) != (a.x2 != nullptr)) return hipErrorInvalidValue;
 #define X(L, CIN, CS, COUT) \
-    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_edge_inst<L, CIN, CS, COUT>(a, b_pad, s);
+    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_edge_inst<L, CIN, CS, COUT>(a, b_pad, k_split, s);
     CLD_WINO1D_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;

@@ -413,20 +413,37 @@ static bool takes_halves(int l_in, int c_out, int b_pad) {
     const int tail = nfull % WINO1D_HALVES_BELOW;
     return nfull < WINO1D_HALVES_BELOW || (tail != 0 && tail <= WINO1D_HALVES_BELOW / 2);
 }
-long wino1d_row_planes(int l_in, int c_out, int b_pad, bool whole_items) {
-    if (WINO1D_EDGE && (whole_items || !takes_halves(l_in, c_out, b_pad))) return wino1d_edge_row_planes(l_in, b_pad);
-    return 8L * wino1d_gemm_rows(l_in, b_pad);
+// ... except that a launch of about one whole item per CU runs whole items of EIGHT waves (wino1d_edge.hip, KS = 2: the two halves of the
+// input channels on four waves each): two waves per SIMD without fetching any weight plane or staging any row twice
+#ifndef WINO1D_KSPLIT_MIN
+#define WINO1D_KSPLIT_MIN 192
+#endif
+static bool takes_ksplit(int l_in, int c_out, int b_pad) {
+    const int nfull = b_pad / (l_in == 13 ? 16 : 8) * (c_out / 64);
+    return nfull >= WINO1D_KSPLIT_MIN && nfull <= 256;
+}
+// 0: half items, 1: whole items, 2: whole items of eight waves
+static int item_form_of(int l_in, int c_out, int b_pad, int forced) {
+    if (!WINO1D_EDGE) return takes_halves(l_in, c_out, b_pad) ? 0 : 3;
+    if (forced) return forced;
+    if (takes_ksplit(l_in, c_out, b_pad)) return 2;
+    return takes_halves(l_in, c_out, b_pad) ? 0 : 1;
+}
+long wino1d_row_planes(int l_in, int c_out, int b_pad, int item_form) {
+    const int f = item_form_of(l_in, c_out, b_pad, item_form);
+    return f == 1 || f == 2 ? wino1d_edge_row_planes(l_in, b_pad) : 8L * wino1d_gemm_rows(l_in, b_pad);
 }
 
 template <int L, int CIN, int CS, int COUT>
-static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, bool whole_items, hipStream_t s) {
+static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, int item_form, hipStream_t s) {
     typedef W1Geo<L, CIN, CS, COUT> G;
     const int groups = b_pad / G::AG, nfull = groups * G::NCB;
-    const bool halves = !(WINO1D_EDGE && whole_items) && takes_halves(L, COUT, b_pad);
-    if (WINO1D_EDGE && !halves) {
+    const int form = item_form_of(L, COUT, b_pad, item_form);
+    const bool halves = form == 0;
+    if (form == 1 || form == 2) {
         ConvArgs e = a;
         e.wfrag = a.wfrag_edge;
-        return e.wfrag ? launch_wino1d_edge(e, L, b_pad, s) : hipErrorInvalidValue;
+        return e.wfrag ? launch_wino1d_edge(e, L, b_pad, form == 2, s) : hipErrorInvalidValue;
     }
     auto kern_whole = wino1d_conv_kernel<L, CIN, CS, COUT, 0>;
     auto kern_half = wino1d_conv_kernel<L, CIN, CS, COUT, 1>;
@@ -440,10 +457,10 @@ static hipError_t launch_wino1d_inst(const ConvArgs& a, int b_pad, bool whole_it
     return hipGetLastError();
 }
 
-hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, bool whole_items, hipStream_t s) {
+hipError_t launch_wino1d(const ConvArgs& a, int l_in, int b_pad, int item_form, hipStream_t s) {
     if (b_pad < 16 || b_pad % 16 || a.res4_x || a.c1_real != a.c1_pad || (a.c2 != 0) != (a.x2 != nullptr)) return hipErrorInvalidValue;
 #define X(L, CIN, CS, COUT) \
-    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_inst<L, CIN, CS, COUT>(a, b_pad, whole_items, s);
+    if (l_in == L && a.c1_real == CS && a.c1_real + a.c2 == CIN && a.c_out == COUT) return launch_wino1d_inst<L, CIN, CS, COUT>(a, b_pad, item_form, s);
     CLD_WINO1D_INSTANCES(X)
 #undef X
     return hipErrorInvalidValue;

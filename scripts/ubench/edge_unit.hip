@@ -47,11 +47,33 @@ int main(int argc, char** argv) {
     (void)hipMemset(dy, 0xff, (size_t)B * L * N * 4);
     cld::ConvArgs a{};
     a.x1 = dx; a.c1_real = C; a.c1_pad = C; a.wfrag = dw; a.bias = db; a.gamma = dg; a.beta = dbe; a.y = dy; a.c_out = N; a.ly = L;
-    hipError_t e = cld::launch_wino1d_edge(a, L, B, 0);
+    hipError_t e = cld::launch_wino1d_edge(a, L, B, false, 0);
     (void)hipDeviceSynchronize();
     printf("launch: %s / %s\n", hipGetErrorString(e), hipGetErrorString(hipGetLastError()));
     std::vector<float> y((size_t)B * L * N);
     (void)hipMemcpy(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost);
+    if (argc > 4) {      // timing mode: <L> <C_in> <C_out> <rows>: the launch with its weight planes warm in L2 / Infinity Cache vs after 1 GB of other traffic
+        const int BT = atoi(argv[4]);
+        float *tx, *ty, *flush;
+        (void)hipMalloc(&tx, (size_t)BT * L * C * 4); (void)hipMalloc(&ty, (size_t)BT * L * N * 4); (void)hipMalloc(&flush, (size_t)1 << 30);
+        (void)hipMemset(tx, 0, (size_t)BT * L * C * 4);
+        cld::ConvArgs t = a; t.x1 = tx; t.y = ty;
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int mode = 0; mode < 2; ++mode) {
+            float tot = 0;
+            for (int it = 0; it < 12; ++it) {
+                if (mode == 1) (void)hipMemsetAsync(flush, it, (size_t)1 << 30, 0);
+                (void)hipEventRecord(e0, 0);
+                (void)cld::launch_wino1d_edge(t, L, BT, false, 0);
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (it >= 2) tot += ms;
+            }
+            printf("%s: %.1f us per launch (%d rows)\n", mode ? "after 1 GB of other traffic" : "back to back (weights and rows warm)", tot / 10 * 1e3, BT);
+        }
+        return 0;
+    }
     const int GS = N / 8;
     double all = 0;
     for (int b = 0; b < B; ++b) {

@@ -29,7 +29,7 @@ def _engine(n=100, jitter=True, form="winograd"):
 
 # "winograd": half items (wino1d_kernels.hip) at these sizes; "winograd_whole": wino1d_edge.hip's whole items, which a launch takes by itself
 # only from two workgroups per CU (the large-batch cases below) -- forced here so that the golden fixtures and the oracle cover that kernel too
-ITEM_FORMS = ["winograd", "winograd_whole"]
+ITEM_FORMS = ["winograd", "winograd_whole", "winograd_ksplit"]
 
 
 @pytest.fixture(scope="module", params=ITEM_FORMS)
@@ -154,6 +154,8 @@ def test_winograd_is_the_default_for_large_launch_sets_and_agrees_with_the_direc
     whole = e.unet_forward(x, cond, 41).clone()
     if B == 4096:                                    # 512 whole items or more in every k5 launch of the two levels: what the size rule takes is the whole-item kernel
         assert torch.equal(whole, wino)
+        perm = torch.randperm(B, generator=g)        # a row's result does not depend on its place in a workgroup (16 agent rows; at L = 26 a pair of rows per agent): bit for bit
+        assert torch.equal(e.unet_forward(x[perm], cond[perm], 41).cpu(), whole.cpu()[perm])
     elif B <= 2100:                                  # every launch in half items (the other Winograd kernel: its fourth tile where this one has a direct column)
         assert not torch.equal(whole, wino)
     assert float((whole - wino).abs().max()) <= 1e-5

@@ -210,7 +210,7 @@ def test_force_kernel_tables_match_header():
     for name, macro in kernels.items():
         assert _lib.KERNELS[name] == defs["CLD_KERNEL_" + macro], name
     forms = {"auto": "AUTO", "valu": "VALU", "mfma": "MFMA", "quad": "MFMA_QUAD", "layers": "LAYERS", "chain": "CHAIN", "chain1": "CHAIN_TILE1",
-             "chain4": "CHAIN_TILE4", "chainw": "CHAIN_WINO", "chainw2": "CHAIN_WINO2", "chainw1": "CHAIN_WINO1", "direct": "DIRECT", "winograd": "WINOGRAD", "winograd_whole": "WINOGRAD_WHOLE"}
+             "chain4": "CHAIN_TILE4", "chainw": "CHAIN_WINO", "chainw2": "CHAIN_WINO2", "chainw1": "CHAIN_WINO1", "direct": "DIRECT", "winograd": "WINOGRAD", "winograd_whole": "WINOGRAD_WHOLE", "winograd_ksplit": "WINOGRAD_KSPLIT"}
     assert set(_lib.FORMS) == set(forms)
     for name, macro in forms.items():
         assert _lib.FORMS[name] == defs["CLD_FORM_" + macro], name
@@ -240,7 +240,8 @@ def test_conv5_form_rule_and_its_32_bit_fallback():
         assert f(l, c1, c2, co, 4096, AUTO) == DIRECT and f(l, c1, c2, co, 4096, WINO) == DIRECT
     WHOLE = _lib.FORMS["winograd_whole"]                 # whole items at every size: a Winograd form, the same rule
     assert f(13, 256, 0, 256, 16, WHOLE) == WINO and f(52, 64, 0, 64, 4096, WHOLE) == DIRECT
-    assert f(13, 256, 0, 256, -1, AUTO) < 0 and f(13, 256, 0, 256, 64, 4) < 0
+    assert f(13, 256, 0, 256, 16, _lib.FORMS["winograd_ksplit"]) == WINO
+    assert f(13, 256, 0, 256, -1, AUTO) < 0 and f(13, 256, 0, 256, 64, 5) < 0
 
 
 def test_timers_keep_the_reference_surface():
