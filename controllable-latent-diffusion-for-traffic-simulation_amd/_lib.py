@@ -33,7 +33,7 @@ OPTIMIZERS = {"adam": 0, "sgd": 1}
 KERNELS = {"guide": 0, "decode": 1, "encode": 2, "unet": 3, "context": 4, "conv5": 5}        # cld_debug_force_kernel
 FORMS = {"auto": 0, "valu": 1, "mfma": 2, "quad": 3,         # "quad": guide kernel only
          "layers": 1, "chain": 2, "chain1": 3, "chain4": 4, "chainw": 5, "chainw2": 6, "chainw1": 7,                              # "unet" only: one launch per layer / LDS-resident layer chains
-         "direct": 1, "winograd": 2, "winograd_whole": 3, "winograd_ksplit": 4}                                                     # "context": the 3x3 / stride-1 convolutions of the ResNet-18; "conv5": the 256 -> 256 k5 layers of the U-Net
+         "direct": 1, "winograd": 2, "winograd_whole": 3, "winograd_ksplit": 4, "winograd_f2": 3}                                                     # "context": the 3x3 / stride-1 convolutions of the ResNet-18; "conv5": the 256 -> 256 k5 layers of the U-Net
 
 
 class CldGuidance(C.Structure):

@@ -12,7 +12,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC ${CLD_EXTRA_FLAGS:-} $*"
 TAG=$(echo "$FLAGS" | md5sum | cut -c1-8)
 OBJ=build/obj_$TAG
 mkdir -p "$OBJ"
-SRCS="conv_block conv_chain chain_wino misc_kernels context_kernels wino_kernels wino1d_kernels wino1d_edge guide_kernels collision_kernels cld_api"
+SRCS="conv_block conv_chain chain_wino misc_kernels context_kernels wino_kernels wino44_kernels wino1d_kernels wino1d_edge guide_kernels collision_kernels cld_api"
 pids=()
 for s in $SRCS; do
     src=csrc/$s.hip

@@ -77,7 +77,7 @@ struct cld_handle_s {
     EncoderWeights enc{};
     bool has_encoder = false;
     // ContextEncoder (optional): stem, 19 NHWC convolutions, head
-    struct Conv2dLayer { float *wfrag = nullptr, *ufrag = nullptr, *scale = nullptr, *shift = nullptr; int kh = 3, stride = 1, hin = 56, cin = 64, cout = 64; };   // ufrag: the Winograd-domain filters of a 3x3 / stride-1 layer (wino_kernels.hip)
+    struct Conv2dLayer { float *wfrag = nullptr, *ufrag = nullptr, *ufrag44 = nullptr, *scale = nullptr, *shift = nullptr; int kh = 3, stride = 1, hin = 56, cin = 64, cout = 64; };   // ufrag: the Winograd-domain filters of a 3x3 / stride-1 layer (wino_kernels.hip)
     bool has_context = false;
     float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
     Conv2dLayer rn_conv[4][2][2], rn_ds[4];
@@ -789,7 +789,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes) {
 }
 
 int cld_debug_force_kernel(cld_handle h, int32_t which, int32_t form) {
-    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE ? 3 : which == CLD_KERNEL_CONV5 ? 4 : (which == CLD_KERNEL_UNET ? 7 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
+    if (!h || which < 0 || which > 5 || form < 0 || form > (which == CLD_KERNEL_GUIDE || which == CLD_KERNEL_CONTEXT ? 3 : which == CLD_KERNEL_CONV5 ? 4 : (which == CLD_KERNEL_UNET ? 7 : 2))) return fail(h, CLD_ERR_ARG, "cld_debug_force_kernel: bad argument");
     h->force_kernel[which] = form;
     return CLD_OK;
 }
@@ -1205,6 +1205,25 @@ int cld_finalize(cld_handle h, void* stream) {
                 auto uget = [&](int co, int ci, int xi) -> float { return U[((size_t)xi * cin + ci) * cout + co]; };
                 std::vector<float> upacked = pack_conv_weights(uget, cout, cin, 16);
                 UP(l.ufrag, upacked);
+                if (wino44_supported(hin, cout)) {
+                    // Winograd F(4x4, 3x3) at the points {0, 1, -1, 1/2, -2, inf} (wino44_kernels.hip): U[xi = 6 i + j] = (G g G^T)[i][j], in double
+                    static const double G6[6][3] = {{1, 0, 0}, {1.0 / 3, 1.0 / 3, 1.0 / 3}, {-1.0 / 3, 1.0 / 3, -1.0 / 3},
+                                                    {-16.0 / 15, -8.0 / 15, -4.0 / 15}, {1.0 / 15, -2.0 / 15, 4.0 / 15}, {0, 0, 1}};
+                    std::vector<float> U6((size_t)36 * cin * cout);
+                    for (int co = 0; co < cout; ++co)
+                        for (int ci = 0; ci < cin; ++ci) {
+                            const float* g = &W[((size_t)co * cin + ci) * 9];
+                            double t[6][3];
+                            for (int i = 0; i < 6; ++i)
+                                for (int bb = 0; bb < 3; ++bb) t[i][bb] = G6[i][0] * g[bb] + G6[i][1] * g[3 + bb] + G6[i][2] * g[6 + bb];
+                            for (int i = 0; i < 6; ++i)
+                                for (int j = 0; j < 6; ++j)
+                                    U6[((size_t)(6 * i + j) * cin + ci) * cout + co] = (float)(t[i][0] * G6[j][0] + t[i][1] * G6[j][1] + t[i][2] * G6[j][2]);
+                        }
+                    auto u6get = [&](int co, int ci, int xi) -> float { return U6[((size_t)xi * cin + ci) * cout + co]; };
+                    std::vector<float> u6packed = pack_conv_weights(u6get, cout, cin, 36);
+                    UP(l.ufrag44, u6packed);
+                }
             }
             return fold_bn(bnname, &l.scale, &l.shift);
         };
@@ -1715,16 +1734,16 @@ constexpr int kCtxChunk = 256;                               // agents per pass:
 constexpr size_t kStemFloats = (size_t)112 * 112 * 64;       // per agent
 constexpr size_t kActFloats = (size_t)56 * 56 * 64;          // largest post-pool activation per agent
 
-// Agents per pass of the ContextEncoder.  The Winograd kernels (wino_kernels.hip) run n * (784 | 196 | 49 | 16) / 32 * (C / 64) equal
-// workgroups per launch, two to a CU: at n = 256 that is 12.25 / 6.125 / 3.06 / 2 generations of 512 -- the last generation of the 14x14
-// launches is 6 % full and costs a whole one.  At n = 250 the counts are 11.96 / 5.98 / 2.99 / 1.95.  The pass size is the one that
-// minimises the modelled generation count of the whole batch (a generation of the 56x56 / 28x28 / 14x14 / 7x7 launches lasts 1 / 2 / 4 / 8
-// units: 4 / 8 / 16 / 32 K chunks), with a fixed cost per pass for its 27 launches.
+// Agents per pass of the ContextEncoder.  The Winograd kernels run equal workgroups, two to a CU: n * (196 | 49) / 16 * (C / 64) at 56x56 /
+// 28x28 (wino44_kernels.hip, 4x4 tiles), n * (49 | 16) / 32 * (C / 64) at 14x14 / 7x7 (wino_kernels.hip, 2x2 tiles): at n = 256 that is 6.125 /
+// 3.06 / 3.06 / 2 generations of 512 -- a last generation that is 6 % full costs a whole one.  The pass size is the one that minimises the
+// modelled generation count of the whole batch (a generation of the 56x56 / 28x28 / 14x14 / 7x7 launches lasts 1.6 / 3.1 / 4 / 8 units -- measured:
+// 38 / 68 / 87 / 143 us --), with a fixed cost per pass for its 27 launches.
 int context_pass_size(int B) {
     if (B <= kCtxChunk) return B;
     auto cost = [](int n) {
-        auto gens = [&](int tiles_per_agent, int ncb) { return (long)((n * tiles_per_agent + 31) / 32 * ncb + 511) / 512; };
-        return 4 * gens(784, 1) * 1 + 3 * gens(196, 2) * 2 + 3 * gens(49, 4) * 4 + 3 * gens(16, 8) * 8 + 6;
+        auto gens = [&](int tiles_per_agent, int per_wg, int ncb) { return (long)((n * tiles_per_agent + per_wg - 1) / per_wg * ncb + 511) / 512; };
+        return 4 * gens(196, 16, 1) * 16 + 3 * gens(49, 16, 2) * 31 + 3 * gens(49, 32, 4) * 40 + 3 * gens(16, 32, 8) * 80 + 60;
     };
     int best = kCtxChunk;
     long best_cost = -1;
@@ -1756,7 +1775,9 @@ int cld_context_encode(cld_handle h, const float* image, const float* curr_state
     float* buf[3];
     for (int i = 0; i < 3; ++i) buf[i] = y1 + (size_t)cb * kStemFloats + (size_t)i * cb * kActFloats;
     const bool wino = h->force_kernel[CLD_KERNEL_CONTEXT] != CLD_FORM_DIRECT;
+    const bool wino44 = h->force_kernel[CLD_KERNEL_CONTEXT] != CLD_FORM_WINOGRAD_F2;      // F(4x4, 3x3) where the map is whole 4x4 tiles (56x56, 28x28)
     auto run = [&](const cld_handle_s::Conv2dLayer& l, const float* x, const float* res, float* y, int relu, int n) {
+        if (wino && wino44 && l.ufrag44) return launch_wino44_conv(l.hin, l.cout, WinoArgs{x, l.ufrag44, l.scale, l.shift, res, y, n, relu}, s);
         if (wino && l.ufrag) return launch_wino_conv(l.hin, l.cout, WinoArgs{x, l.ufrag, l.scale, l.shift, res, y, n, relu}, s);
         return launch_conv2d(l.kh, l.stride, l.hin, x, l.wfrag, l.scale, l.shift, res, y, n, l.cin, l.cout, relu, s);
     };

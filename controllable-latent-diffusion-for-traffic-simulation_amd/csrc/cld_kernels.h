@@ -271,6 +271,9 @@ struct WinoArgs {
     int B, relu;
 };
 hipError_t launch_wino_conv(int hin, int channels, const WinoArgs& a, hipStream_t s);
+// the same layers at 56x56 / 28x28 by F(4x4, 3x3) (wino44_kernels.hip): a.ufrag = the 36-plane fragments (Conv2dLayer::ufrag44)
+bool wino44_supported(int hin, int channels);
+hipError_t launch_wino44_conv(int hin, int channels, const WinoArgs& a, hipStream_t s);
 struct ContextHeadArgs {
     const float* feat;          // [B,7,7,512] NHWC, layer4 output
     const float* curr_states;   // [B,4]

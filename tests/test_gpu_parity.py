@@ -338,6 +338,18 @@ def test_context_winograd_and_direct_convolutions_agree(eng_ctx, B):
     scale = float(md.abs().max())
     assert float((md - mw).abs().max()) <= 2e-5 * scale
     assert float((cd - cw).abs().max()) <= 2e-5
+    # round 4: the 56x56 and 28x28 layers of the Winograd form run as F(4x4, 3x3) (wino44_kernels.hip); F(2x2, 3x3) for every layer -- last
+    # round's form -- on request: a third kernel set, the same function to the same bars
+    try:
+        eng_ctx.force_kernel("context", "winograd_f2")
+        c2, m2 = eng_ctx.context_encode(img.cuda(), cs.cuda(), want_map_feat=True)
+        c2, m2 = c2.clone(), m2.clone()
+    finally:
+        eng_ctx.force_kernel("context", "auto")
+    assert not torch.equal(m2, mw)
+    print(f"context B={B}: max|F(4x4) - direct| = {float((md - mw).abs().max()) / scale:.2e}, max|F(2x2) - direct| = {float((md - m2).abs().max()) / scale:.2e} of max|map_feat|")
+    assert float((m2 - mw).abs().max()) <= 2e-5 * scale and float((md - m2).abs().max()) <= 2e-5 * scale
+    assert float((c2 - cw).abs().max()) <= 2e-5
     if B <= 5:
         taps = {}
         ref = O.context_encode(O.to_torch(synth.make_context_weights(0)), img, cs, taps)

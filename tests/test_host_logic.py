@@ -210,7 +210,7 @@ def test_force_kernel_tables_match_header():
     for name, macro in kernels.items():
         assert _lib.KERNELS[name] == defs["CLD_KERNEL_" + macro], name
     forms = {"auto": "AUTO", "valu": "VALU", "mfma": "MFMA", "quad": "MFMA_QUAD", "layers": "LAYERS", "chain": "CHAIN", "chain1": "CHAIN_TILE1",
-             "chain4": "CHAIN_TILE4", "chainw": "CHAIN_WINO", "chainw2": "CHAIN_WINO2", "chainw1": "CHAIN_WINO1", "direct": "DIRECT", "winograd": "WINOGRAD", "winograd_whole": "WINOGRAD_WHOLE", "winograd_ksplit": "WINOGRAD_KSPLIT"}
+             "chain4": "CHAIN_TILE4", "chainw": "CHAIN_WINO", "chainw2": "CHAIN_WINO2", "chainw1": "CHAIN_WINO1", "direct": "DIRECT", "winograd": "WINOGRAD", "winograd_whole": "WINOGRAD_WHOLE", "winograd_ksplit": "WINOGRAD_KSPLIT", "winograd_f2": "WINOGRAD_F2"}
     assert set(_lib.FORMS) == set(forms)
     for name, macro in forms.items():
         assert _lib.FORMS[name] == defs["CLD_FORM_" + macro], name
