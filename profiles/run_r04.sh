@@ -22,7 +22,7 @@ python3 $R/scripts/collision_time.py > $OUT/collision_time.txt 2>&1 && \
 python3 $R/scripts/guide_time.py 1024 2048 4096 > $OUT/guide_time.txt 2>&1 && \
 python3 $R/scripts/sweep_batch.py 8 64 128 256 512 768 1024 1536 2048 4096 8192 > $OUT/batch_sweep.txt 2>&1 && \
 CLD_SWEEP_CONV5=direct python3 $R/scripts/sweep_batch.py 512 768 1024 2048 4096 > $OUT/batch_sweep_direct_form.txt 2>&1 && \
-python3 $R/scripts/ctx_time.py 1024 winograd > $OUT/ctx_time_1024.txt 2>&1 && python3 $R/scripts/ctx_time.py 1024 direct >> $OUT/ctx_time_1024.txt 2>&1 && \
+python3 $R/scripts/ctx_time.py 1024 winograd > $OUT/ctx_time_1024.txt 2>&1 && python3 $R/scripts/ctx_time.py 1024 winograd_f2 >> $OUT/ctx_time_1024.txt 2>&1 && python3 $R/scripts/ctx_time.py 1024 direct >> $OUT/ctx_time_1024.txt 2>&1 && \
 python3 $R/bench.py --workload configs1 --no-cpu-baseline --no-extras > $OUT/bench_n1_configs1.json 2> $OUT/err1 && \
 python3 $R/bench.py --workload configs3 --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_n1_configs3.json 2> $OUT/err3 && \
 python3 $R/bench.py --workload configs4 --scenes 64 --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_n1_configs4_shard.json 2> $OUT/err4 && \
@@ -34,6 +34,7 @@ ARGS="$R/bench.py --steps 1 --warmup 0 --denoise-steps 10 --no-cpu-baseline --no
 CLD_LIB_PATH=$R/controllable-latent-diffusion-for-traffic-simulation_amd/libcld_stamps.so python3 $R/scripts/wino1d_stamps.py 4096 3 8 13 18 > $OUT/wino1d_stamps_4096.txt 2>&1
 CLD_LIB_PATH=$R/controllable-latent-diffusion-for-traffic-simulation_amd/libcld_stamps.so python3 $R/scripts/chainw_stamps.py 4096 > $OUT/chainw_stamps_4096.txt 2>&1
 $R/scripts/ubench/mfma_covalu > $OUT/mfma_covalu.txt 2>&1
+$R/scripts/ubench/w44_unit 56 256 > $OUT/wino44_stamps.txt 2>&1; $R/scripts/ubench/w44_unit 28 256 >> $OUT/wino44_stamps.txt 2>&1
 bash $R/scripts/wino_pmc.sh winograd > $OUT/ctx_clock_mfma_busy.txt 2>&1; bash $R/scripts/wino_pmc.sh direct >> $OUT/ctx_clock_mfma_busy.txt 2>&1
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o p -- python3 $ARGS > $OUT/pmc_sq.log 2>&1 && \

@@ -9,7 +9,7 @@ SRC, DST = os.path.join(ROOT, "gpurun_out", "r04"), os.path.join(ROOT, "profiles
 os.makedirs(DST, exist_ok=True)
 
 for f in ("bench_n1.json", "bench_n1_configs1.json", "bench_n1_configs3.json", "bench_n1_configs4_shard.json", "bench_n2_gloo_rehearsal.json",
-          "batch_sweep.txt", "batch_sweep_direct_form.txt", "ctx_time_1024.txt", "wino1d_stamps_4096.txt", "ctx_clock_mfma_busy.txt",
+          "batch_sweep.txt", "batch_sweep_direct_form.txt", "ctx_time_1024.txt", "wino1d_stamps_4096.txt", "wino44_stamps.txt", "ctx_clock_mfma_busy.txt",
           "guide_time.txt", "unet_B64.txt", "unet_B1024.txt", "unet_B2048.txt", "unet_B4096.txt", "chain_check.txt", "collision_time.txt",
           "chainw_stamps_4096.txt", "mfma_covalu.txt"):
     if os.path.exists(os.path.join(SRC, f)):
