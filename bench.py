@@ -272,9 +272,11 @@ def main():
                 traffic = pmc_traffic(rows) if not split else (None, None)
                 wino = not split and rows >= 384          # csrc/cld_api.hip kWino1dMinRows: the Winograd F(4, 5) form of these launches
 
-                def wino_whole(r):                        # csrc/wino1d_kernels.hip takes_halves: whole items from two workgroups per CU
+                def wino_item_form(r):                    # csrc/wino1d_kernels.hip item_form_of: 1 whole items, 2 whole items of eight waves, 0 half items
                     nfull = (r + 15) // 16 * 4
-                    return not (nfull < 512 or 0 < nfull % 512 <= 256)
+                    if 192 <= nfull <= 256:
+                        return 2
+                    return 0 if (nfull < 512 or 0 < nfull % 512 <= 256) else 1
                 what = ("Conv1d 256 -> 256 ch, k5 + GroupNorm + Mish at L=13; 7 launches per U-Net evaluation, all with 256 input channels "
                         "-- every 10th evaluation timed")
                 # `achieved` / `frac`: FLOP the MFMA pipe EXECUTED (counted by the library for the form each timed launch took:
@@ -286,8 +288,8 @@ def main():
                         "frac": round(ex_ach / peak, 4), "traffic": traffic[0], "traffic_source": traffic[1],
                         "peak_basis": ("v_mfma_f32_16x16x32_f16 dense peak / 3 (three MFMAs per algorithmic product)" if split
                                        else "v_mfma_f32_16x16x4_f32 dense peak"),
-                        "kernel": (("wino1d_edge_kernel<13,256,256,256> (%s; rows of agents, output 12 of every row in the direct form)" if wino_whole(rows)
-                                    else "wino1d_conv_kernel<13,256,256,256,1> (%s; half items)") % what if wino else
+                        "kernel": (("wino1d_edge_kernel<13,256,256,256,%d> (%%s; rows of agents, output 12 of every row in the direct form)" % wino_item_form(rows)
+                                    if wino_item_form(rows) else "wino1d_conv_kernel<13,256,256,256,1> (%s; half items)") % what if wino else
                                    "conv_block_kernel<13,13,1,5,32,%s,1,32,1,0,0,0,0> (%s; tiling picked by the rows per launch)"
                                    % ("4,1" if rows >= 2048 else ("4,2" if rows >= 1024 else "2,2"), what)),
                         "agents_per_launch": rows, "launches": int(launches), "avg_us": round(ms * 1e3 / launches, 2),

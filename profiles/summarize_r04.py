@@ -46,7 +46,7 @@ def avg(kernel_sub, counter):
 
 
 out = {}
-dom = "wino1d_edge_kernel<13, 256, 256, 256>"     # the 256 -> 256 k5 launches in their Winograd form: the headline launches 4,096 rows (2 x 2,048 agents, CFG)
+dom = "wino1d_edge_kernel<13, 256, 256, 256, 1>"     # the 256 -> 256 k5 launches in their Winograd form: the headline launches 4,096 rows (2 x 2,048 agents, CFG)
 fe, wr = avg(dom, "FETCH_SIZE"), avg(dom, "WRITE_SIZE")
 if fe is not None and wr is not None:
     out = {"kernel": "void cld::" + dom + "(cld::ConvArgs, int, int)", "batch_agents": 4096,
