@@ -29,6 +29,10 @@
 // workgroup (the xi split between wave pairs, two M-tiles per wave, half the weight traffic) measured the same.
 #include "cld_kernels.h"
 
+#ifndef W44_EXP
+#define W44_EXP 0      // experiment builds of scripts/ubench/w44_unit.hip only: 1 no patch loads in the loop, 2 no rows pass, 4 no columns pass / LDS stores (results are wrong)
+#endif
+
 
 // (wino_kernels.hip) a tile's result must not depend on its place in the workgroup: no implicit contraction
 #pragma clang fp contract(off)
@@ -184,13 +188,22 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
     for (int q = 0; q < 3; ++q) rows_pass(q);
 #pragma unroll
     for (int j = 0; j < 6; ++j) cols_pass(j, 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) patch_load(r, c, 1);
     __syncthreads();
     W44STAMP(1);
 
-    // one chunk: 36 xi x 4 MFMAs.  V fragments run two positions ahead of their MFMAs (a rolling window of three), U fragments four; the next
-    // chunk's patch is requested during xi = 0 .. 17 (two values per position), its rows pass (two rows at a time) runs at xi = 22, 24, 26, its
-    // columns pass (with the stores into the other image) at xi = 28 .. 33
-    auto mfma_block = [&](const int buf, const int c, const bool stage) {
+    // one chunk: 36 xi x 4 MFMAs.  V fragments run two positions ahead of their MFMAs (a rolling window of three), U fragments four.  The patch of
+    // the NEXT chunk is in registers when a block starts: its rows pass (two rows at a time) runs at xi = 10, 12, 14, its columns pass (with the
+    // stores into the other image) at xi = 16 .. 21, and the patch of the chunk after that is requested in ONE go at xi = 35, behind the block's last
+    // weight-fragment request.  Loads return in order: a weight fragment requested behind patch loads is not usable before they have landed.  With
+    // the patch requests spread over the first half of a block (two per position) every position there waited for a trip to HBM that had started
+    // four positions earlier -- the block ran at the pace of the memory system (a chunk pair with staging 35k cycles, without 17k); requested in
+    // one go at the end, the fragments of the next block's first four positions are already on their way and only what is left of ONE trip after a
+    // barrier and four positions is exposed.
+    auto mfma_block = [&](const int buf, const int c, const bool stage1, const bool stage2) {
         const int bo = buf * (G::VBUF * 4);
         auto frag = [&](const int xi) { return *reinterpret_cast<const v4f*>(ldsb + abase + bo + xi * 1024); };
         v4f ar[3];
@@ -201,12 +214,12 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
             const v4f bcur = bq[xi & 3];
             bq[xi & 3] = wload(c * 36 + xi + 4);
             if (xi + 2 < 36) ar[(xi + 2) % 3] = frag(xi + 2);
-            if (stage && xi < 18) {
-                patch_load((2 * xi) / 6, (2 * xi) % 6, c + 1);
-                patch_load((2 * xi + 1) / 6, (2 * xi + 1) % 6, c + 1);
+            if (!(W44_EXP & 2) && stage1 && xi >= 10 && xi < 16 && (xi & 1) == 0) rows_pass((xi - 10) >> 1);
+            if (!(W44_EXP & 4) && stage1 && xi >= 16 && xi < 22) cols_pass(xi - 16, buf ^ 1);
+            if (!(W44_EXP & 1) && stage2 && xi == 35) {      // behind the block's last weight fragment request
+#pragma unroll
+                for (int i = 0; i < 36; ++i) patch_load(i / 6, i % 6, c + 2);
             }
-            if (stage && xi >= 22 && xi < 28 && (xi & 1) == 0) rows_pass((xi - 22) >> 1);
-            if (stage && xi >= 28 && xi < 34) cols_pass(xi - 28, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[xi] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[e], ar[xi % 3][e], acc[xi], 0, 0, 0);
@@ -216,10 +229,10 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
 
 #pragma clang loop unroll(disable)
     for (int c = 0; c < G::NCH; c += 2) {
-        mfma_block(0, c, true);
-        __syncthreads();
         const bool more = c + 2 < G::NCH;
-        mfma_block(1, c + 1, more);
+        mfma_block(0, c, true, more);
+        __syncthreads();
+        mfma_block(1, c + 1, more, more);
         __syncthreads();
         if (c == 0) W44STAMP(2);
     }
