@@ -311,3 +311,41 @@ def test_bench_cli_parses_without_a_gpu():
     assert out.returncode == 0, out.stderr
     for flag in ("--gpus", "--steps", "--warmup", "--cfg-w", "--guide", "--closed-loop", "--precision", "--no-context"):
         assert flag in out.stdout
+
+
+def test_minimal_filtering_matrices_of_the_kernels_reproduce_the_direct_form():
+    """The transform matrices the Winograd kernels are written from (csrc/wino1d_kernels.hip / wino1d_edge.hip: F(4, 5) at {0, +-1, +-2, +-1/2, inf};
+    csrc/wino44_kernels.hip: F(4x4, 3x3) at {0, 1, -1, 1/2, -2, inf}; G as csrc/cld_api.hip forms U), checked in fp64 against the direct
+    correlation -- including wino1d_edge.hip's split of a 13-long row into three tiles and one direct output (27 products per channel pair)."""
+    rng = np.random.default_rng(0)
+    # ---- F(4, 5): y[4 t .. 4 t + 3] = A^T [(G g) (.) (B^T d)], d = x[4 t - 2 .. 4 t + 5]
+    BT = np.array([[-1, 0, 21 / 4, 0, -21 / 4, 0, 1, 0], [0, 1, 1, -17 / 4, -17 / 4, 1, 1, 0], [0, -1, 1, 17 / 4, -17 / 4, -1, 1, 0],
+                   [0, 1 / 2, 1 / 4, -5 / 2, -5 / 4, 2, 1, 0], [0, -1 / 2, 1 / 4, 5 / 2, -5 / 4, -2, 1, 0], [0, 2, 4, -5 / 2, -5, 1 / 2, 1, 0],
+                   [0, -2, 4, 5 / 2, -5, -1 / 2, 1, 0], [0, -1, 0, 21 / 4, 0, -21 / 4, 0, 1]])
+    G = np.array([[-1, 0, 0, 0, 0], [-2 / 9] * 5, [-2 / 9, 2 / 9, -2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45, 4 / 45, 8 / 45],
+                  [1 / 90, -1 / 45, 2 / 45, -4 / 45, 8 / 45], [32 / 45, 16 / 45, 8 / 45, 4 / 45, 2 / 45], [32 / 45, -16 / 45, 8 / 45, -4 / 45, 2 / 45], [0, 0, 0, 0, 1]])
+    AT = np.array([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1 / 2, -1 / 2, 0], [0, 1, 1, 4, 4, 1 / 4, 1 / 4, 0], [0, 1, -1, 8, -8, 1 / 8, -1 / 8, 1]])
+    g = rng.standard_normal(5)
+    x = rng.standard_normal(13)
+    xp = np.concatenate([np.zeros(2), x, np.zeros(6)])                 # pad 2 | 13 values | zeros past the end
+    ref = np.array([sum(g[k] * xp[l + k] for k in range(5)) for l in range(13)])
+    y = np.empty(13)
+    for t in range(3):                                                  # outputs 0 .. 11: three tiles, 8 products each
+        y[4 * t:4 * t + 4] = AT @ ((G @ g) * (BT @ xp[4 * t:4 * t + 8]))
+    y[12] = sum(g[k] * x[10 + k] for k in range(3))                     # output 12 in the direct form: taps 3, 4 meet the padding
+    assert np.abs(y - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    src = open(os.path.join(ROOT, "controllable-latent-diffusion-for-traffic-simulation_amd", "csrc", "cld_api.hip")).read()
+    assert "{32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45}" in src and "{1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45}" in src
+    # ---- F(4x4, 3x3): Y = A^T [(G g G^T) (.) (B^T d B)] A, d = the 6x6 patch at rows / columns 4 t - 1 .. 4 t + 4
+    BT6 = np.array([[1, -3 / 2, -2, 3 / 2, 1, 0], [0, -1, 1 / 2, 5 / 2, 1, 0], [0, 1, -5 / 2, 1 / 2, 1, 0], [0, -2, -1, 2, 1, 0], [0, 1 / 2, -1, -1 / 2, 1, 0],
+                    [0, 1, -3 / 2, -2, 3 / 2, 1]])
+    G6 = np.array([[1, 0, 0], [1 / 3, 1 / 3, 1 / 3], [-1 / 3, 1 / 3, -1 / 3], [-16 / 15, -8 / 15, -4 / 15], [1 / 15, -2 / 15, 4 / 15], [0, 0, 1]])
+    AT6 = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 1 / 2, -2, 0], [0, 1, 1, 1 / 4, 4, 0], [0, 1, -1, 1 / 8, -8, 1]])
+    g2 = rng.standard_normal((3, 3))
+    d = rng.standard_normal((6, 6))
+    Y = AT6 @ ((G6 @ g2 @ G6.T) * (BT6 @ d @ BT6.T)) @ AT6.T
+    ref2 = np.array([[sum(g2[a, b] * d[i + a, j + b] for a in range(3) for b in range(3)) for j in range(4)] for i in range(4)])
+    assert np.abs(Y - ref2).max() <= 1e-12 * max(1.0, np.abs(ref2).max())
+    assert "{-16.0 / 15, -8.0 / 15, -4.0 / 15}, {1.0 / 15, -2.0 / 15, 4.0 / 15}" in src
+    for M in (BT, AT, BT6, AT6):                                        # exact in fp32: the kernels apply them with fp32 constants
+        assert np.array_equal(M.astype(np.float32).astype(np.float64), M)
