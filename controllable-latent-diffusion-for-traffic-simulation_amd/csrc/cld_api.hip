@@ -1734,16 +1734,16 @@ constexpr int kCtxChunk = 256;                               // agents per pass:
 constexpr size_t kStemFloats = (size_t)112 * 112 * 64;       // per agent
 constexpr size_t kActFloats = (size_t)56 * 56 * 64;          // largest post-pool activation per agent
 
-// Agents per pass of the ContextEncoder.  The Winograd kernels run equal workgroups, two to a CU: n * (196 | 49) / 16 * (C / 64) at 56x56 /
-// 28x28 (wino44_kernels.hip, 4x4 tiles), n * (49 | 16) / 32 * (C / 64) at 14x14 / 7x7 (wino_kernels.hip, 2x2 tiles): at n = 256 that is 6.125 /
-// 3.06 / 3.06 / 2 generations of 512 -- a last generation that is 6 % full costs a whole one.  The pass size is the one that minimises the
-// modelled generation count of the whole batch (a generation of the 56x56 / 28x28 / 14x14 / 7x7 launches lasts 1.6 / 3.1 / 4 / 8 units -- measured:
-// 38 / 68 / 87 / 143 us --), with a fixed cost per pass for its 27 launches.
+// Agents per pass of the ContextEncoder.  The Winograd kernels (wino44_kernels.hip, 4x4 tiles) run equal workgroups of 16 tiles x 64 channels, two
+// to a CU: n * (196 | 49 | 16 | 4) / 16 * (C / 64) at 56x56 / 28x28 / 14x14 / 7x7 -- at n = 256 that is 6.125 / 3.06 / 2 / 1 generations of 512; a last
+// generation that is 6 % full costs a whole one.  The pass size is the one that minimises the modelled generation count of the whole batch (a
+// generation of the four launch kinds lasts 1.5 / 2.7 / 4.3 / 8.5 units -- measured: 36 / 65 / 103 / 202 us --), with a fixed cost per pass for its
+// 27 launches.  (With CLD_FORM_WINOGRAD_F2 the counts of wino_kernels.hip differ; the pass size is a speed choice only.)
 int context_pass_size(int B) {
     if (B <= kCtxChunk) return B;
     auto cost = [](int n) {
-        auto gens = [&](int tiles_per_agent, int per_wg, int ncb) { return (long)((n * tiles_per_agent + per_wg - 1) / per_wg * ncb + 511) / 512; };
-        return 4 * gens(196, 16, 1) * 16 + 3 * gens(49, 16, 2) * 31 + 3 * gens(49, 32, 4) * 40 + 3 * gens(16, 32, 8) * 80 + 60;
+        auto gens = [&](int tiles_per_agent, int ncb) { return (long)((n * tiles_per_agent + 15) / 16 * ncb + 511) / 512; };
+        return 4 * gens(196, 1) * 15 + 3 * gens(49, 2) * 27 + 3 * gens(16, 4) * 43 + 3 * gens(4, 8) * 85 + 60;
     };
     int best = kCtxChunk;
     long best_cost = -1;

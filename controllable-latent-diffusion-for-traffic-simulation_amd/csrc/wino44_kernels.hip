@@ -62,13 +62,14 @@ namespace {
 
 template <int HIN>
 struct W44Geo {
-    static constexpr int C = HIN == 56 ? 64 : 128;
-    static constexpr int TH = HIN / 4, TPA = TH * TH;            // 4x4 tiles per row / per agent: 14 / 196, 7 / 49
+    static constexpr int C = HIN == 56 ? 64 : HIN == 28 ? 128 : HIN == 14 ? 256 : 512;
+    static constexpr int TH = (HIN + 3) / 4, TPA = TH * TH;      // 4x4 tiles per row / per agent: 14 / 196, 7 / 49, 4 / 16, 2 / 4
+    static constexpr bool EXACT = HIN % 4 == 0;                   // 14x14 and 7x7: the last tile row / column hangs over the edge (16x16, 8x8 covered)
     static constexpr int MT = 16, KC = 16;                        // tiles per workgroup: one M-tile
     static constexpr int NCH = C / KC, NCB = C / 64, NTN = C / 16;
     static constexpr int VBUF = 36 * MT * KC;                     // floats per V image
     static constexpr size_t LDS_BYTES = 2 * VBUF * sizeof(float);
-    static_assert(HIN == 56 || HIN == 28, "maps that are whole numbers of 4x4 tiles");
+    static_assert(HIN == 56 || HIN == 28 || HIN == 14 || HIN == 7, "resnet18 feature maps");
     static_assert(NCH % 2 == 0, "chunk pairs are unrolled");
 };
 
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
     // tensor's <= 206 MB, the range check returns 0); so does every element of a tile past the end of the list
     constexpr unsigned kOut = 1u << 30;
     constexpr int ROWB = HIN * G::C * 4, COLB = G::C * 4;           // bytes between patch rows / columns
-    unsigned vbase, vrow0, vrow5, coff0, coff5;
+    // (14x14 / 7x7: the last tile row / column hangs over the edge, so rows / columns 3 and 4 can be padding too and get offset registers as
+    //  well; 1 and 2 are inside for every tile of every map)
+    unsigned vbase, vrow0, vrow3, vrow4, vrow5, coff0, coff3, coff4, coff5;
     {
         const int T = tile0 + ts;
         const int a = T / G::TPA, rem = T % G::TPA, ty = rem / G::TH, tx = rem % G::TH;
@@ -136,16 +139,18 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
 #ifdef W44_EXP_HOT
         vbase = (unsigned)(((4 * HIN + 4) * G::C + c1) * 4);      // experiment: every tile reads the same patch (always in L1 / L2)
 #endif
-        vrow0 = ty > 0 ? vbase - (unsigned)ROWB : kOut;
-        vrow5 = ty < G::TH - 1 ? vbase + (unsigned)(4 * ROWB) : kOut;
-        coff0 = tx > 0 ? 0u - (unsigned)COLB : kOut;
-        coff5 = tx < G::TH - 1 ? (unsigned)(4 * COLB) : kOut;
+        auto rowoff = [&](const int r) { const int iy = 4 * ty - 1 + r; return (iy >= 0 && iy < HIN) ? vbase + (unsigned)((r - 1) * ROWB) : kOut; };
+        auto coloff = [&](const int c) { const int ix = 4 * tx - 1 + c; return (ix >= 0 && ix < HIN) ? (unsigned)((c - 1) * COLB) : kOut; };
+        vrow0 = rowoff(0); vrow3 = rowoff(3); vrow4 = rowoff(4); vrow5 = rowoff(5);
+        coff0 = coloff(0); coff3 = coloff(3); coff4 = coloff(4); coff5 = coloff(5);
     }
     v2f44 dp[3][6];                                                  // the patch in row pairs -- dp[q][c] = (d[2 q][c], d[2 q + 1][c]) --, then d B in place
     auto patch_load = [&](const int r, const int c, const int chunk) {
-        const unsigned vr = r == 0 ? vrow0 : r == 5 ? vrow5 : vbase;
-        const unsigned vo = c == 0 ? vr + coff0 : c == 5 ? vr + coff5 : vr + (unsigned)((c - 1) * COLB);
-        const int so = chunk * (G::KC * 4) + (r >= 1 && r <= 4 ? (r - 1) * ROWB : 0);
+        const bool rreg = r == 0 || r == 5 || (!G::EXACT && r >= 3), creg = c == 0 || c == 5 || (!G::EXACT && c >= 3);
+        const unsigned vr = r == 0 ? vrow0 : r == 5 ? vrow5 : (rreg && r == 3) ? vrow3 : (rreg && r == 4) ? vrow4 : vbase;
+        const unsigned co = c == 0 ? coff0 : c == 5 ? coff5 : c == 3 ? coff3 : coff4;
+        const unsigned vo = creg ? vr + co : vr + (unsigned)((c - 1) * COLB);
+        const int so = chunk * (G::KC * 4) + (rreg ? 0 : (r - 1) * ROWB);
         dp[r >> 1][c][r & 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (int)vo, so, 0));
     };
     const int wofs = ts * 16 + ((((ts >> 2) & 3) ^ hsw4(c1 >> 2)) << 2) + (c1 & 3);
@@ -258,6 +263,11 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
     const int a = T / G::TPA, rem = T % G::TPA, ty = rem / G::TH, tx = rem % G::TH;
     const bool has_res = p.res != nullptr;
     const int o0 = (((a * HIN + 4 * ty) * HIN + 4 * tx) * G::C + n4) * 4;      // byte offset of the tile's first output (the tensors are < 2^31 bytes)
+    const int nrow = HIN - 4 * ty, ncol = HIN - 4 * tx;                       // outputs of the tile inside the map (>= 4 except on the ragged maps' last row / column)
+    auto ooff = [&](const int oy, const int ox) {                             // an output past the edge: an offset past the tensor (the load returns 0, the store is dropped)
+        const int off = o0 + oy * ROWB + ox * COLB;
+        return (G::EXACT || (oy < nrow && ox < ncol)) ? off : (int)kOut;
+    };
     const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_res ? p.res : p.y), 0, total_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, total_bytes, 0x00020000);
     // the 16 residual values are requested in one go, behind M A (the accumulators are dead): one offset register, output rows in the scalar
@@ -265,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
     v4f rv[16];
     if (has_res) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) rv[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsr, o0 + (k & 3) * COLB, (k >> 2) * ROWB, 0));
+        for (int k = 0; k < 16; ++k) rv[k] = G::EXACT ? __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsr, o0 + (k & 3) * COLB, (k >> 2) * ROWB, 0))
+                               : __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsr, ooff(k >> 2, k & 3), 0, 0));
     }
     const v4f sc = *reinterpret_cast<const v4f*>(p.scale + n4), sh = *reinterpret_cast<const v4f*>(p.shift + n4);
 #pragma unroll
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wino44_conv_kernel(const WinoArgs p) {
             if (has_res) v += rv[4 * oy + ox];
             if (p.relu) v = v4f{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
             // (16-byte stores keep their distances in the VECTOR offset: wino1d_edge.hip)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v44, v), rsy, o0 + oy * ROWB + ox * COLB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v44, v), rsy, ooff(oy, ox), 0, 0);
         }
     }
     W44STAMP(6);
@@ -298,13 +309,15 @@ static hipError_t launch_wino44_inst(const WinoArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-bool wino44_supported(int hin, int channels) { return (hin == 56 && channels == 64) || (hin == 28 && channels == 128); }
+bool wino44_supported(int hin, int channels) { return (hin == 56 && channels == 64) || (hin == 28 && channels == 128) || (hin == 14 && channels == 256) || (hin == 7 && channels == 512); }
 
 // a.ufrag: U = G g G^T of F(4x4, 3x3), 36 planes per 16-channel chunk (cld_api.hip, Conv2dLayer::ufrag44)
 hipError_t launch_wino44_conv(int hin, int channels, const WinoArgs& a, hipStream_t s) {
     if (a.B < 1 || a.B > 256) return hipErrorInvalidValue;          // byte offsets are 32-bit: one pass of the encoder at a time
     if (hin == 56 && channels == 64) return launch_wino44_inst<56>(a, s);
     if (hin == 28 && channels == 128) return launch_wino44_inst<28>(a, s);
+    if (hin == 14 && channels == 256) return launch_wino44_inst<14>(a, s);
+    if (hin == 7 && channels == 512) return launch_wino44_inst<7>(a, s);
     return hipErrorInvalidValue;
 }
 
