@@ -1,10 +1,11 @@
-// wino44_kernels.hip -- the 3x3 stride-1 convolutions of the ContextEncoder's ResNet-18 at 56x56 (64 channels) and 28x28 (128 channels)
-// (reference: torchvision resnet18 built at src/tbsim/models/base_models.py:559-614, called from models/context_utils.py:40-61) by
+// wino44_kernels.hip -- the thirteen 3x3 stride-1 convolutions of the ContextEncoder's ResNet-18 (64 channels @ 56x56, 128 @ 28x28, 256 @ 14x14,
+// 512 @ 7x7; reference: torchvision resnet18 built at src/tbsim/models/base_models.py:559-614, called from models/context_utils.py:40-61) by
 // Winograd's minimal filtering F(4x4, 3x3).
 //
-// wino_kernels.hip runs these layers as F(2x2, 3x3): 16 multiplies per 2x2 outputs, 2.25x fewer than the direct form.  Both maps are whole
-// numbers of 4x4 tiles (14 x 14 and 7 x 7), and on 4x4 tiles the same construction needs 36 multiplies per 16 outputs: **4x fewer than the
-// direct form, 1.78x fewer MFMAs than F(2x2, 3x3)**.  What decides whether that is usable in fp32 is the choice of points.  With
+// wino_kernels.hip runs these layers as F(2x2, 3x3): 16 multiplies per 2x2 outputs, 2.25x fewer than the direct form.  On 4x4 tiles the same
+// construction needs 36 multiplies per 16 outputs: **4x fewer than the direct form, 1.78x fewer MFMAs than F(2x2, 3x3)** where the map is a
+// whole number of tiles (56x56: 14 x 14 tiles, 28x28: 7 x 7) and at 7x7 (2 x 2 tiles over 8x8, which F(2x2) covers too), 1.36x at 14x14 (4 x 4 tiles
+// over 16x16).  What decides whether that is usable in fp32 is the choice of points.  With
 // {0, +-1, +-2, inf} (the textbook set) or {0, +-1, +-1/2, inf} the rounding error of a 64-channel layer is 4 - 9e-6 of max|y| against
 // fp64; with **{0, 1, -1, 1/2, -2, inf}** -- reciprocal pairs of opposite sign -- it is 2 - 3e-6 (the direct form: 0.7 - 1.5e-6,
 // F(2x2, 3x3): 0.4e-6; numpy model of the kernel's arithmetic, 64 and 128 channels), inside the bars the encoder is held to:

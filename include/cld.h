@@ -480,7 +480,7 @@ int cld_debug_lds_floor(cld_handle h, size_t bytes);
 #define CLD_FORM_DIRECT 1     /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 #define CLD_FORM_WINOGRAD 2   /* CLD_KERNEL_CONTEXT, CLD_KERNEL_CONV5 */
 #define CLD_FORM_WINOGRAD_F2 3  /* CLD_KERNEL_CONTEXT only: F(2x2, 3x3) for every stride-1 3x3 convolution (wino_kernels.hip); CLD_FORM_AUTO / CLD_FORM_WINOGRAD
-                                 * take F(4x4, 3x3) at 56x56 and 28x28 (wino44_kernels.hip) and F(2x2, 3x3) at 14x14 and 7x7 */
+                                 * take F(4x4, 3x3) (wino44_kernels.hip) */
 #define CLD_FORM_WINOGRAD_KSPLIT 4  /* CLD_KERNEL_CONV5 only: whole items run by eight waves (the two halves of the input channels on four waves each) at every
                                      * launch size: what CLD_FORM_WINOGRAD takes by itself for launches of about one whole item per CU */
 #define CLD_FORM_WINOGRAD_WHOLE 3   /* CLD_KERNEL_CONV5 only: Winograd with whole items at every launch size (wino1d_edge.hip: what CLD_FORM_WINOGRAD takes
